@@ -1,0 +1,152 @@
+/*
+ * msr.h — C-ABI of the MI355X-native learned-sparse retrieval scorer.
+ *
+ * This is the drop-in boundary for the reference's sparse search step. In the reference
+ * (cjc20000323/mllm_sparse_retrieval) that step is three calls into pyserini/Anserini/Lucene:
+ *
+ *     LuceneImpactSearcher(index_dir, None)              src/search.py:273
+ *     searcher.set_analyzer(JWhiteSpaceAnalyzer())       src/search.py:274-275
+ *     searcher.batch_search(queries, qids, k, threads)   src/search.py:86-87
+ *
+ * plus the offline index build `python -m pyserini.index.lucene --impact --pretokenized`
+ * (scripts/sparse_index.sh:12-18) over the jsonl written by src/encode.py:351-359,426.
+ * Each entry point below names the reference interface it replaces.
+ *
+ * Conventions
+ *   - plain C, no C++/torch types; every function returns 0 (MSR_OK) or a negative MSR_E_* code and
+ *     never throws; msr_last_error() returns a thread-local message for the last failure.
+ *   - the caller allocates every output array; the library owns only opaque handles and device buffers.
+ *   - one in-flight call per handle (each index handle owns one HIP stream); handles are not thread-safe.
+ *   - all integers little-endian, fixed width. Doc "ordinals" are ranks of the external doc-id strings in
+ *     bytewise ascending order, so "lower ordinal wins a score tie" is the declared tie rule T1
+ *      by construction.
+ *   - scoring is exact unsigned 32-bit integer arithmetic on the GPU; a query whose worst-case score
+ *     could exceed 2^32-1 is rejected with MSR_E_OVERFLOW rather than computed inexactly.
+ *   - there is NO CPU scoring path in this library: searching a handle opened with device < 0, or on a
+ *     machine without a usable HIP device, fails with MSR_E_NODEVICE.
+ */
+#ifndef MSR_H
+#define MSR_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MSR_OK 0
+#define MSR_E_INVAL (-1)    /* bad argument */
+#define MSR_E_IO (-2)       /* file could not be read / written */
+#define MSR_E_FORMAT (-3)   /* malformed jsonl line or index file */
+#define MSR_E_NOMEM (-4)    /* host or device allocation failed */
+#define MSR_E_NODEVICE (-5) /* no HIP device bound to this handle */
+#define MSR_E_HIP (-6)      /* a HIP runtime call failed */
+#define MSR_E_OVERFLOW (-7) /* worst-case score of a query exceeds 2^32-1 */
+#define MSR_E_RANGE (-8)    /* term id / weight / k outside the supported range */
+#define MSR_E_COMM (-9)     /* RCCL failure */
+
+/* search flags */
+#define MSR_F_DROP_DF_EQ_N 1u /* drop query terms present in every doc (pyserini idf>min_idf filter, contract T3) */
+
+#define MSR_KMAX 1024 /* largest supported k (reference default depth is 1000, src/arguments.py:59) */
+
+typedef struct msr_index msr_index; /* an opened (optionally device-resident) inverted index */
+typedef struct msr_batch msr_batch; /* a device-resident batch of CSR queries + its result buffers */
+
+typedef struct msr_info {
+    uint64_t n_docs;        /* docs in the whole index */
+    uint64_t n_postings;    /* (term,doc) pairs with weight > 0 in the whole index */
+    uint64_t n_vecs;        /* 16-byte posting vectors stored (postings + per-segment padding) */
+    uint32_t n_terms;       /* dictionary size */
+    uint32_t tile_docs;     /* docs per tile (accumulator tile held in LDS) */
+    uint32_t n_tiles;       /* tiles in the whole index */
+    uint32_t max_weight;    /* largest stored weight */
+    uint32_t shard_tile0;   /* first tile resident on this handle */
+    uint32_t shard_ntiles;  /* tiles resident on this handle */
+    int32_t device;         /* HIP device ordinal, or -1 */
+    int32_t reserved;
+} msr_info;
+
+/* ---- index build: replaces scripts/sparse_index.sh:12-18 (pyserini.index.lucene --impact --pretokenized) ----
+ * Reads every *.jsonl / *.json file of `jsonl_dir` (lines {"id":…,"content":…,"vector":{tok:int}} as written by
+ * src/encode.py:351-359,426) and writes one index file. tile_docs = 0 picks the default (32768). */
+int msr_index_build(const char* jsonl_dir, const char* out_path, int threads, uint32_t tile_docs);
+
+/* Same index from a doc-major CSR already in memory (used by the synthetic encode step and the benchmark).
+ * doc_ids / term_strs may be NULL: docs are then named by their decimal row number and terms by their decimal id. */
+int msr_index_build_csr(const char* out_path, uint64_t n_docs, uint32_t n_terms, const uint64_t* doc_ptr,
+                        const uint32_t* term_id, const uint32_t* weight, const char* const* doc_ids,
+                        const char* const* term_strs, int threads, uint32_t tile_docs);
+
+/* ---- open / close: replaces LuceneImpactSearcher(index_dir, None), src/search.py:273 ----
+ * device >= 0 uploads the postings to that HIP device; device = -1 opens host-side metadata only
+ * (dictionary, df, doc ids) — such a handle cannot search. */
+int msr_index_open(const char* path, int device, msr_index** out);
+
+/* Doc-range shard `shard` of `n_shards` (contiguous tile range): only that slice of the
+ * postings is uploaded. Ordinals in results stay global. */
+int msr_index_open_shard(const char* path, int device, int shard, int n_shards, msr_index** out);
+
+void msr_index_close(msr_index* ix);
+int msr_index_info(const msr_index* ix, msr_info* info);
+
+/* token -> term id (-1 = not in the index vocabulary); the host-side half of pyserini's query encoding
+ * that src/search.py:86-87 triggers. */
+int msr_term_lookup(const msr_index* ix, const char* const* toks, int n, int32_t* term_ids);
+int msr_term_df(const msr_index* ix, const int32_t* term_ids, int n, uint32_t* df);
+int msr_term_str(const msr_index* ix, uint32_t term_id, const char** s);
+/* external doc id of an ordinal: `hit.docid`, src/search.py:97. Borrowed pointer, valid until close. */
+int msr_docid_str(const msr_index* ix, uint32_t ord, const char** s);
+
+/* ---- search: replaces searcher.batch_search(queries, qids, k, threads), src/search.py:86-87 ----
+ * Queries are CSR: query i owns entries [q_ptr[i], q_ptr[i+1]) of (q_term, q_w). Entries with q_term < 0
+ * (out-of-vocabulary) or q_w <= 0 are ignored; duplicate terms add (src/search.py:419-422).
+ * Outputs (row-major [nq][k]): doc ordinals, scores as f32 (`hit.score`), optional exact u32 scores,
+ * and out_n[i] = number of hits of query i (only docs with score > 0 are hits, so out_n[i] <= k). */
+int msr_search_csr(msr_index* ix, const int64_t* q_ptr, const int32_t* q_term, const int32_t* q_w, int nq, int k,
+                   uint32_t flags, uint32_t* out_doc_ord, float* out_score, uint32_t* out_score_u32,
+                   int32_t* out_n);
+
+/* ---- resident batches: the same search with inputs and outputs kept in HBM (benchmark, pipelining) ---- */
+int msr_batch_create(msr_index* ix, const int64_t* q_ptr, const int32_t* q_term, const int32_t* q_w, int nq,
+                     int kmax, uint32_t flags, msr_batch** out);
+int msr_batch_search(msr_batch* b, int k); /* enqueue on the index's stream; returns before completion */
+int msr_batch_sync(msr_batch* b);
+int msr_batch_fetch(msr_batch* b, uint32_t* out_doc_ord, float* out_score, uint32_t* out_score_u32,
+                    int32_t* out_n); /* syncs, then copies the last search's results ([nq][k]) */
+/* HIP-event durations of the last msr_batch_search on its own stream (ms): the scoring kernel and the merge. */
+int msr_batch_kernel_ms(msr_batch* b, float* score_ms, float* merge_ms);
+/* Algorithmic bytes of one search of this batch, SURVEY.md §8d:
+ * sum over queries of  sum_t df(t)*(4+2) + |q|*12 + k*8  (df restricted to this handle's shard). */
+int msr_batch_algo_bytes(const msr_batch* b, int k, uint64_t* bytes, uint64_t* postings);
+void msr_batch_destroy(msr_batch* b);
+
+/* ---- multi-GPU exchange (doc-range shards, one RCCL all-gather of per-shard top-k) ----
+ * No counterpart in the reference (it never shards the sparse index, src/search.py:216,273). */
+#define MSR_COMM_ID_BYTES 128
+int msr_comm_unique_id(char id[MSR_COMM_ID_BYTES]);
+int msr_comm_init(msr_index* ix, int n_ranks, int rank, const char id[MSR_COMM_ID_BYTES]);
+/* local search + all-gather + merge; afterwards msr_batch_fetch returns the GLOBAL top-k on every rank. */
+int msr_batch_search_sharded(msr_batch* b, int k);
+int msr_comm_destroy(msr_index* ix);
+
+/* Merge `n_lists` per-shard result lists (each [nq][k] as written by msr_batch_fetch) on the device of `ix`
+ * with the same tie rule; used by the host-side exchange (torch.distributed all_gather) and by tests. */
+int msr_merge_lists(msr_index* ix, int n_lists, int nq, int k, const uint32_t* doc_ord, const uint32_t* score_u32,
+                    const int32_t* n, uint32_t* out_doc_ord, float* out_score, uint32_t* out_score_u32,
+                    int32_t* out_n);
+
+/* ---- synthetic encode step (SURVEY.md §8d generator; stands in for src/encode.py when no MLLM is present) ----
+ * Fills a doc-major CSR of n vectors with `nnz` distinct terms each, drawn without replacement from
+ * p(r) ~ r^-zipf_s over n_terms, weights max(1, rint(100*ln(1+x))), x ~ LogNormal(0.5, 0.6), clipped to [1,400].
+ * ptr has n+1 entries; term/weight have n*nnz. Deterministic in (seed, row) regardless of threads. */
+int msr_synth_vectors(uint64_t n, uint32_t nnz, uint32_t n_terms, double zipf_s, uint64_t seed, int threads,
+                      uint64_t* ptr, uint32_t* term, uint32_t* weight);
+
+const char* msr_last_error(void);
+const char* msr_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MSR_H */

@@ -1,0 +1,1051 @@
+// HIP search path for gfx950 (MI355X): device residency of the tile-major inverted index, the scoring kernel,
+// the top-k merge kernel, resident query batches and the RCCL exchange for doc-range shards.
+//
+// Replaces what runs below `LuceneImpactSearcher.batch_search(queries, qids, k, threads)` in the reference
+// (call site src/search.py:86-87; Lucene impact scoring):
+//     score(d) = sum over query terms t of  q_w(t) * tf(t, d),   top-k of the docs with score > 0,
+//     ties broken by external doc id ascending (= lower ordinal).
+//
+// Kernel 1  score_tiles<TILE_DOCS, NT>   one workgroup per (doc tile, query)
+//     - TILE_DOCS u32 accumulators in LDS (128 KiB at 32768 docs),
+//     - the query's (term, tile) segments are cut into 1-KiB "chunks" (64 lanes x 16 B = 256 postings);
+//       waves take chunks round-robin, each lane loads one uint4 (4 postings) and issues 4 ds_add_u32,
+//     - exact per-tile top-k: a lower bound from the per-thread maxima prunes the tile to a few dozen
+//       candidates, which are ranked by counting on unique 64-bit keys (score << 32 | ~ordinal);
+//       a bisection over (score, ordinal) keys is the always-correct fallback (many ties / large k).
+//     Workgroups are ordered tile-major, so the ~512 workgroups in flight score the SAME tile for
+//     different queries and the tile's hot segments are served from the XCDs' L2s, not from HBM.
+// Kernel 2  merge_lists<NT>              one workgroup per query: exact top-k of the per-tile (or per-shard) lists.
+//
+// Roofline: HBM; no MFMA anywhere — this is gather / integer reduce.
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+
+#include <algorithm>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "msr_internal.h"
+
+namespace msr {
+
+#define HIP_TRY(expr)                                                                          \
+    do {                                                                                       \
+        hipError_t _e = (expr);                                                                \
+        if (_e != hipSuccess) {                                                                \
+            set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+            return MSR_E_HIP;                                                                  \
+        }                                                                                      \
+    } while (0)
+
+// ------------------------------------------------------------------------------------------------ constants
+constexpr int kQtBlock = 256;    // query terms staged in LDS per round
+constexpr int kMapCap = 4096;    // chunk -> term map entries per round
+constexpr int kCandCap = 1024;   // candidate keys per workgroup (>= MSR_KMAX)
+constexpr int kChunkVecs = 64;   // one chunk = one wave-wide uint4 load = 256 postings = 1 KiB
+static_assert(kCandCap >= MSR_KMAX, "candidate buffer must hold k keys");
+
+struct DeviceIndex {
+    int device = -1;
+    hipStream_t stream = nullptr;
+    uint32_t* d_seg_ptr = nullptr;   // [shard_ntiles][n_terms+1] absolute vec index
+    uint32_t* d_postings = nullptr;  // the shard's vecs; vec v of the index lives at d_postings + (v - vec_base)*4
+    uint32_t vec_base = 0;
+    uint64_t shard_vecs = 0;
+    std::vector<uint32_t> df_shard;  // postings of each term inside this shard (for algorithmic bytes)
+    bool df_shard_ready = false;
+    // exchange
+    ncclComm_t comm = nullptr;
+    int n_ranks = 1;
+    int rank = 0;
+};
+
+// ------------------------------------------------------------------------------------------------ device helpers
+__device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = max(v, (uint32_t)__shfl_xor(v, o, 64));
+    return v;
+}
+__device__ __forceinline__ uint64_t wave_max_u64(uint64_t v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        uint64_t other = __shfl_xor(v, o, 64);
+        v = other > v ? other : v;
+    }
+    return v;
+}
+
+// Rank-by-counting over `n` UNIQUE non-zero keys in LDS: key with rank r < k goes to out[r]; slots [n, k) get 0.
+template <int NT>
+__device__ __forceinline__ void rank_and_emit(const uint64_t* cand, int n, int k, uint64_t* __restrict__ out) {
+    for (int i = threadIdx.x; i < n; i += NT) {
+        const uint64_t me = cand[i];
+        int rank = 0;
+        for (int j = 0; j < n; ++j) rank += cand[j] > me;
+        if (rank < k) out[rank] = me;
+    }
+    for (int i = n + (int)threadIdx.x; i < k; i += NT) out[i] = 0;
+}
+
+struct SelectScratch {
+    uint32_t cnt[64];  // one counter per bisection step
+    uint32_t n_cand;
+    uint32_t tau0;
+    uint32_t smax;
+    uint32_t pad;
+};
+
+// ------------------------------------------------------------------------------------------------ kernel 1
+struct ScoreArgs {
+    const uint32_t* seg_ptr;   // [ntiles][n_terms+1]
+    const uint32_t* postings;  // shard base
+    const uint32_t* q_ptr;     // [nq+1]
+    const uint32_t* q_term;
+    const uint32_t* q_w;
+    uint64_t* part;            // [ntiles][nq][k] keys
+    uint64_t n_docs;           // whole index
+    uint32_t vec_base;
+    uint32_t n_terms;
+    uint32_t tile0;            // first (global) tile of the shard
+    uint32_t nq;
+    uint32_t k;
+};
+
+// LDS carve (bytes). The staging arrays of the streaming phase and the candidate keys of the select phase are
+// never live together, so they share one region.
+template <int TILE_DOCS, int NT>
+struct TileLds {
+    static constexpr int kAcc = TILE_DOCS * 4;
+    static constexpr int kStage = kQtBlock * 4 * 3 + (kQtBlock + 4) * 4 + 8 * 4 + kMapCap;  // seg_start/len/w, pref, wsum, cmap
+    static constexpr int kCand = kCandCap * 8;
+    static constexpr int kUnion = (kStage > kCand ? kStage : kCand);
+    static constexpr int kTmax = NT * 4;
+    static constexpr int kTotal = kAcc + kUnion + kTmax + (int)sizeof(SelectScratch);
+};
+
+template <int TILE_DOCS, int NT, int MIN_WAVES>
+__global__ __launch_bounds__(NT, MIN_WAVES) void score_tiles(const ScoreArgs a) {
+    constexpr int NW = NT / 64;
+    static_assert(TILE_DOCS % (4 * NT) == 0, "tile must be a multiple of 4*NT");
+    static_assert(NT >= kQtBlock, "the staging scan uses the first 256 threads");
+    using L = TileLds<TILE_DOCS, NT>;
+
+    __shared__ __attribute__((aligned(16))) uint8_t lds[L::kTotal];
+    uint32_t* const acc = reinterpret_cast<uint32_t*>(lds);
+    uint8_t* const un = lds + L::kAcc;
+    // streaming-phase view of the union
+    uint32_t* const seg_start = reinterpret_cast<uint32_t*>(un);
+    uint32_t* const seg_len = seg_start + kQtBlock;
+    uint32_t* const seg_w = seg_len + kQtBlock;
+    uint32_t* const pref = seg_w + kQtBlock;
+    uint32_t* const wsum = pref + kQtBlock + 4;
+    uint8_t* const cmap = reinterpret_cast<uint8_t*>(wsum + 8);
+    // select-phase view of the union
+    uint64_t* const cand = reinterpret_cast<uint64_t*>(un);
+    uint32_t* const tmax = reinterpret_cast<uint32_t*>(un + L::kUnion);
+    SelectScratch& ss = *reinterpret_cast<SelectScratch*>(un + L::kUnion + L::kTmax);
+
+    const uint32_t tid = threadIdx.x;
+    const uint32_t lane = tid & 63;
+    const uint32_t wave = tid >> 6;
+    const uint32_t tile_l = blockIdx.x / a.nq;  // tile-major: neighbours in dispatch order share the tile
+    const uint32_t q = blockIdx.x % a.nq;
+    const uint32_t tile_g = a.tile0 + tile_l;
+    const uint64_t doc0 = (uint64_t)tile_g * TILE_DOCS;
+    const uint32_t ndocs_tile = (uint32_t)min((uint64_t)TILE_DOCS, a.n_docs - doc0);
+    // rounds of 4*NT accumulators that hold real docs
+    const int rounds = (int)((ndocs_tile + 4 * NT - 1) / (4 * NT));
+    uint4* const a4 = reinterpret_cast<uint4*>(acc);
+
+    // ---- zero the accumulators that can be touched
+    for (int r = 0; r < rounds; ++r) a4[r * NT + tid] = make_uint4(0, 0, 0, 0);
+    if (tid < 64) ss.cnt[tid] = 0;
+    if (tid == 0) {
+        ss.n_cand = 0;
+        ss.tau0 = 1;
+        ss.smax = 0;
+    }
+
+    const uint32_t qb = a.q_ptr[q], qe = a.q_ptr[q + 1];
+    const uint32_t* seg_row = a.seg_ptr + (uint64_t)tile_l * (a.n_terms + 1);
+    const uint4* post4 = reinterpret_cast<const uint4*>(a.postings);
+
+    for (uint32_t base = qb; base < qe; base += kQtBlock) {
+        const uint32_t cnt = min((uint32_t)kQtBlock, qe - base);
+        __syncthreads();  // previous round's readers of seg_* / cmap are done; zeroing is visible
+        // ---- stage the round's segments and an exclusive prefix sum of their chunk counts
+        uint32_t nch = 0;
+        if (tid < kQtBlock) {
+            if (tid < cnt) {
+                const uint32_t t = a.q_term[base + tid];
+                const uint32_t s0 = seg_row[t], s1 = seg_row[t + 1];
+                seg_start[tid] = s0 - a.vec_base;
+                seg_len[tid] = s1 - s0;
+                seg_w[tid] = a.q_w[base + tid];
+                nch = (s1 - s0 + kChunkVecs - 1) / kChunkVecs;
+            }
+            uint32_t inc = nch;  // inclusive scan inside the wave
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                uint32_t up = __shfl_up(inc, o, 64);
+                if (lane >= (uint32_t)o) inc += up;
+            }
+            if (lane == 63) wsum[wave] = inc;
+            nch = inc - nch;  // exclusive within the wave
+        }
+        __syncthreads();
+        if (tid < kQtBlock) {
+            uint32_t off = 0;
+            for (uint32_t w = 0; w < wave; ++w) off += wsum[w];
+            pref[tid] = nch + off;
+            if (tid == kQtBlock - 1) pref[kQtBlock] = off + wsum[wave];
+        }
+        __syncthreads();
+        const uint32_t total = pref[kQtBlock];
+
+        for (uint32_t c0 = 0; c0 < total; c0 += kMapCap) {
+            const uint32_t cend = min(total, c0 + (uint32_t)kMapCap);
+            if (c0) __syncthreads();  // readers of the previous window are done
+            // ---- chunk -> term map for this window (parallel binary search over pref)
+            for (uint32_t c = c0 + tid; c < cend; c += NT) {
+                uint32_t lo = 0, hi = cnt;  // largest lo with pref[lo] <= c
+                while (hi - lo > 1) {
+                    uint32_t mid = (lo + hi) >> 1;
+                    if (pref[mid] <= c)
+                        lo = mid;
+                    else
+                        hi = mid;
+                }
+                cmap[c - c0] = (uint8_t)lo;
+            }
+            __syncthreads();
+            // ---- stream the chunks: 4 loads in flight per wave, then 16 LDS atomics per lane
+            for (uint32_t c = c0 + wave; c < cend; c += 4 * NW) {
+                uint4 v[4];
+                uint32_t w[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const uint32_t cu = c + u * NW;
+                    v[u] = make_uint4(0, 0, 0, 0);
+                    w[u] = 0;
+                    if (cu < cend) {
+                        const uint32_t j = cmap[cu - c0];
+                        const uint32_t off = (cu - pref[j]) * kChunkVecs + lane;
+                        if (off < seg_len[j]) {
+                            v[u] = post4[seg_start[j] + off];
+                            w[u] = seg_w[j];
+                        }
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    if (w[u]) {
+                        const uint32_t p[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            if (p[e]) atomicAdd(&acc[p[e] & 0xFFFFu], (p[e] >> 16) * w[u]);
+                    }
+                }
+            }
+        }
+    }
+    __syncthreads();  // accumulation complete; the staging view of the union is dead from here on
+
+    // =============================================================== exact top-k of this tile
+    // Thread `tid` owns vec r*NT + tid of the accumulators in round r (conflict-free ds_read_b128); the
+    // accumulators are re-read from LDS in every pass instead of being held in registers.
+    uint64_t* out = a.part + ((uint64_t)tile_l * a.nq + q) * a.k;
+    const int k = (int)a.k;
+
+    uint32_t mymax = 0;
+    for (int r = 0; r < rounds; ++r) {
+        const uint4 x = a4[r * NT + tid];
+        mymax = max(max(mymax, max(x.x, x.y)), max(x.z, x.w));
+    }
+    tmax[tid] = mymax;
+    __syncthreads();
+
+    // ---- wave 0: tau0 = k-th largest thread maximum (a lower bound with >= k accumulators at or above it)
+    if (wave == 0) {
+        uint32_t mine[NW];
+        uint32_t m = 0;
+#pragma unroll
+        for (int i = 0; i < NW; ++i) {
+            mine[i] = tmax[i * 64 + lane];
+            m = max(m, mine[i]);
+        }
+        m = wave_max_u32(m);
+        uint32_t tau = 0;
+        if (k <= NT && m > 0) {
+            for (int bit = 31 - __clz(m); bit >= 0; --bit) {
+                const uint32_t t2 = tau | (1u << bit);
+                uint32_t c = 0;
+#pragma unroll
+                for (int i = 0; i < NW; ++i) c += mine[i] >= t2;
+                c = wave_sum_u32(c);
+                if (c >= (uint32_t)k) tau = t2;
+            }
+        }
+        if (lane == 0) {
+            ss.tau0 = max(tau, 1u);
+            ss.smax = m;
+        }
+    }
+    __syncthreads();
+    const uint32_t tau0 = ss.tau0;
+    const uint32_t smax = ss.smax;
+    if (smax == 0) {  // nothing matched in this tile
+        for (int i = tid; i < k; i += NT) out[i] = 0;
+        return;
+    }
+
+    // ---- candidates: accumulators >= tau0 as unique global keys (score << 32 | ~ordinal)
+    if (mymax >= tau0) {
+        for (int r = 0; r < rounds; ++r) {
+            const uint4 x = a4[r * NT + tid];
+            const uint32_t sc4[4] = {x.x, x.y, x.z, x.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (sc4[e] >= tau0) {
+                    const uint32_t local = 4 * (r * NT + tid) + e;
+                    const uint32_t pos = atomicAdd(&ss.n_cand, 1u);
+                    if (pos < kCandCap)
+                        cand[pos] = ((uint64_t)sc4[e] << 32) | (uint64_t)(0xFFFFFFFFu - (uint32_t)(doc0 + local));
+                }
+        }
+    }
+    __syncthreads();
+    uint32_t n_cand = ss.n_cand;
+
+    if (n_cand > kCandCap) {
+        // ---- fallback: bisection for the k-th largest (score, ordinal) key of the whole tile.
+        // local key = score << 16 | (0xFFFF - local ordinal): unique, so exactly min(k, #positive) survive.
+        __syncthreads();  // everyone has read n_cand
+        if (tid == 0) ss.n_cand = 0;
+        const int top = 16 + (32 - __clz(smax));  // bits in use (<= 48 < 64 counter slots)
+        uint64_t tau = 0;
+        int step = 0;
+        for (int bit = top - 1; bit >= 0; --bit, ++step) {
+            const uint64_t t2 = tau | (1ull << bit);
+            uint32_t c = 0;
+            for (int r = 0; r < rounds; ++r) {
+                const uint4 x = a4[r * NT + tid];
+                const uint32_t sc4[4] = {x.x, x.y, x.z, x.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const uint32_t local = 4 * (r * NT + tid) + e;
+                    const uint64_t key = sc4[e] ? (((uint64_t)sc4[e] << 16) | (0xFFFFu - local)) : 0ull;
+                    c += key >= t2;
+                }
+            }
+            c = wave_sum_u32(c);
+            if (lane == 0 && c) atomicAdd(&ss.cnt[step], c);
+            __syncthreads();
+            if (ss.cnt[step] >= (uint32_t)k) tau = t2;
+        }
+        __syncthreads();
+        for (int r = 0; r < rounds; ++r) {
+            const uint4 x = a4[r * NT + tid];
+            const uint32_t sc4[4] = {x.x, x.y, x.z, x.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const uint32_t local = 4 * (r * NT + tid) + e;
+                const uint64_t key = sc4[e] ? (((uint64_t)sc4[e] << 16) | (0xFFFFu - local)) : 0ull;
+                if (key && key >= tau) {
+                    const uint32_t pos = atomicAdd(&ss.n_cand, 1u);
+                    if (pos < kCandCap)
+                        cand[pos] = ((uint64_t)sc4[e] << 32) | (uint64_t)(0xFFFFFFFFu - (uint32_t)(doc0 + local));
+                }
+            }
+        }
+        __syncthreads();
+        n_cand = min(ss.n_cand, (uint32_t)kCandCap);  // == min(k, #positive) <= kCandCap by construction
+    }
+    rank_and_emit<NT>(cand, (int)n_cand, k, out);
+}
+
+// ------------------------------------------------------------------------------------------------ kernel 2
+struct MergeArgs {
+    const uint64_t* lists;   // key(list, q, j) = lists[list*list_stride + q*k + j]; 0 = empty slot
+    uint64_t list_stride;
+    uint32_t n_lists;
+    uint32_t nq;
+    uint32_t k;
+    uint64_t* out_keys;      // [nq][k] (may be null)
+    uint32_t* out_ord;       // [nq][k] (may be null)
+    uint32_t* out_score_u32;
+    float* out_score;
+    int32_t* out_n;
+};
+
+template <int NT>
+__global__ __launch_bounds__(NT) void merge_lists(const MergeArgs a) {
+    __shared__ __attribute__((aligned(16))) uint64_t cand[kCandCap];
+    __shared__ uint64_t res[kCandCap];
+    __shared__ SelectScratch ss;
+    __shared__ uint64_t wmax[NT / 64];
+
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t q = blockIdx.x;
+    const int k = (int)a.k;
+    const uint32_t n_items = a.n_lists * a.k;
+    auto key_at = [&](uint32_t i) -> uint64_t {
+        const uint32_t l = i / a.k, j = i - l * a.k;
+        return a.lists[(uint64_t)l * a.list_stride + (uint64_t)q * a.k + j];
+    };
+    if (tid < 64) ss.cnt[tid] = 0;
+    if (tid == 0) ss.n_cand = 0;
+    __syncthreads();
+
+    uint32_t n_cand;
+    if (n_items <= kCandCap) {
+        for (uint32_t i = tid; i < n_items; i += NT) {
+            const uint64_t key = key_at(i);
+            if (key) cand[atomicAdd(&ss.n_cand, 1u)] = key;
+        }
+        __syncthreads();
+        n_cand = ss.n_cand;
+    } else {
+        // bisection for the k-th largest key, re-reading the lists from L2 each step
+        uint64_t m = 0;
+        for (uint32_t i = tid; i < n_items; i += NT) {
+            const uint64_t key = key_at(i);
+            m = key > m ? key : m;
+        }
+        m = wave_max_u64(m);
+        if (lane == 0) wmax[wave] = m;
+        __syncthreads();
+        m = 0;
+        for (int w = 0; w < NT / 64; ++w) m = wmax[w] > m ? wmax[w] : m;
+        uint64_t tau = 0;
+        if (m) {
+            int step = 0;
+            for (int bit = 63 - __clzll((long long)m); bit >= 0; --bit, ++step) {
+                const uint64_t t2 = tau | (1ull << bit);
+                uint32_t c = 0;
+                for (uint32_t i = tid; i < n_items; i += NT) c += key_at(i) >= t2;
+                c = wave_sum_u32(c);
+                if (lane == 0 && c) atomicAdd(&ss.cnt[step], c);  // at most 64 steps: one slot each
+                __syncthreads();
+                if (ss.cnt[step] >= (uint32_t)k) tau = t2;
+            }
+        }
+        __syncthreads();
+        for (uint32_t i = tid; i < n_items; i += NT) {
+            const uint64_t key = key_at(i);
+            if (key && key >= tau) {
+                const uint32_t pos = atomicAdd(&ss.n_cand, 1u);
+                if (pos < kCandCap) cand[pos] = key;
+            }
+        }
+        __syncthreads();
+        n_cand = min(ss.n_cand, (uint32_t)kCandCap);
+    }
+    rank_and_emit<NT>(cand, (int)n_cand, k, res);
+    __syncthreads();
+    const int n_hit = min((int)n_cand, k);
+    for (int i = tid; i < k; i += NT) {
+        const uint64_t key = res[i];
+        const uint64_t o = (uint64_t)q * a.k + i;
+        if (a.out_keys) a.out_keys[o] = key;
+        if (a.out_ord) {
+            const uint32_t sc = (uint32_t)(key >> 32);
+            a.out_ord[o] = key ? 0xFFFFFFFFu - (uint32_t)key : 0xFFFFFFFFu;
+            a.out_score_u32[o] = sc;
+            a.out_score[o] = (float)sc;  // round-to-nearest-even, exact below 2^24 (contract T5)
+        }
+    }
+    if (tid == 0 && a.out_n) a.out_n[q] = n_hit;
+}
+
+// ------------------------------------------------------------------------------------------------ launch
+static int launch_score(hipStream_t st, uint32_t tile_docs, uint32_t ntiles, const ScoreArgs& a) {
+    const uint64_t blocks = (uint64_t)ntiles * a.nq;
+    if (blocks == 0) return MSR_OK;
+    if (blocks > 0x7FFFFFFFull) {
+        set_error("too many workgroups (%llu tiles x queries); split the batch", (unsigned long long)blocks);
+        return MSR_E_RANGE;
+    }
+    switch (tile_docs) {
+        // <tile docs, threads, min waves/SIMD>: 32768 -> 1 workgroup/CU (16 waves), 16384 -> 2/CU (16 waves),
+        // 8192 -> 3/CU (12 waves), 4096 -> 4/CU (16 waves)
+        case 32768: hipLaunchKernelGGL((score_tiles<32768, 1024, 4>), dim3((uint32_t)blocks), dim3(1024), 0, st, a); break;
+        case 16384: hipLaunchKernelGGL((score_tiles<16384, 512, 4>), dim3((uint32_t)blocks), dim3(512), 0, st, a); break;
+        case 8192: hipLaunchKernelGGL((score_tiles<8192, 256, 3>), dim3((uint32_t)blocks), dim3(256), 0, st, a); break;
+        case 4096: hipLaunchKernelGGL((score_tiles<4096, 256, 4>), dim3((uint32_t)blocks), dim3(256), 0, st, a); break;
+        default:
+            set_error("no kernel instance for tile_docs=%u (supported: 4096, 8192, 16384, 32768)", tile_docs);
+            return MSR_E_RANGE;
+    }
+    HIP_TRY(hipGetLastError());
+    return MSR_OK;
+}
+
+static int launch_merge(hipStream_t st, const MergeArgs& a) {
+    if (a.nq == 0) return MSR_OK;
+    hipLaunchKernelGGL((merge_lists<256>), dim3(a.nq), dim3(256), 0, st, a);
+    HIP_TRY(hipGetLastError());
+    return MSR_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ residency
+int device_attach(msr_index* ix, int device) {
+    int n_dev = 0;
+    hipError_t e = hipGetDeviceCount(&n_dev);
+    if (e != hipSuccess || n_dev <= 0) {
+        set_error("no usable HIP device (%s); this library has no CPU scoring path",
+                  e != hipSuccess ? hipGetErrorString(e) : "device count is 0");
+        return MSR_E_NODEVICE;
+    }
+    if (device >= n_dev) {
+        set_error("HIP device %d requested but only %d present", device, n_dev);
+        return MSR_E_NODEVICE;
+    }
+    const IndexHeader* h = ix->host.h;
+    switch (h->tile_docs) {
+        case 4096: case 8192: case 16384: case 32768: break;
+        default:
+            set_error("index tile_docs=%u has no kernel instance (supported: 4096, 8192, 16384, 32768)", h->tile_docs);
+            return MSR_E_RANGE;
+    }
+    DeviceIndex* d = new (std::nothrow) DeviceIndex;
+    if (!d) {
+        set_error("out of host memory");
+        return MSR_E_NOMEM;
+    }
+    d->device = device;
+    ix->dev = d;
+    ix->device = device;
+    auto fail = [&](int rc) {
+        device_detach(ix);
+        return rc;
+    };
+    if (hipSetDevice(device) != hipSuccess) {
+        set_error("hipSetDevice(%d) failed", device);
+        return fail(MSR_E_HIP);
+    }
+    if (hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking) != hipSuccess) {
+        set_error("hipStreamCreate failed");
+        return fail(MSR_E_HIP);
+    }
+    const uint64_t stride = (uint64_t)h->n_terms + 1;
+    const uint32_t t0 = ix->shard_tile0, nt = ix->shard_ntiles;
+    if (nt) {
+        const uint32_t* sp = ix->host.seg_ptr + (uint64_t)t0 * stride;
+        d->vec_base = sp[0];
+        d->shard_vecs = (uint64_t)sp[(uint64_t)(nt - 1) * stride + h->n_terms] - d->vec_base;
+        const size_t seg_bytes = (size_t)nt * stride * 4;
+        const size_t post_bytes = std::max<size_t>((size_t)d->shard_vecs * 16, 16);
+        if (hipMalloc(&d->d_seg_ptr, seg_bytes) != hipSuccess || hipMalloc(&d->d_postings, post_bytes) != hipSuccess) {
+            set_error("hipMalloc of %zu + %zu bytes for the index shard failed", seg_bytes, post_bytes);
+            return fail(MSR_E_NOMEM);
+        }
+        if (hipMemcpy(d->d_seg_ptr, sp, seg_bytes, hipMemcpyHostToDevice) != hipSuccess ||
+            (d->shard_vecs && hipMemcpy(d->d_postings, ix->host.postings + (uint64_t)d->vec_base * 4,
+                                        (size_t)d->shard_vecs * 16, hipMemcpyHostToDevice) != hipSuccess)) {
+            set_error("upload of the index shard failed");
+            return fail(MSR_E_HIP);
+        }
+    }
+    return MSR_OK;
+}
+
+void device_detach(msr_index* ix) {
+    DeviceIndex* d = ix->dev;
+    if (!d) return;
+    (void)hipSetDevice(d->device);
+    if (d->comm) ncclCommDestroy(d->comm);
+    if (d->d_seg_ptr) (void)hipFree(d->d_seg_ptr);
+    if (d->d_postings) (void)hipFree(d->d_postings);
+    if (d->stream) (void)hipStreamDestroy(d->stream);
+    delete d;
+    ix->dev = nullptr;
+}
+
+// postings of every term inside the shard: 4*vecs minus the zero padding of each segment's last vec
+static void compute_df_shard(msr_index* ix) {
+    DeviceIndex* d = ix->dev;
+    if (d->df_shard_ready) return;
+    const IndexHeader* h = ix->host.h;
+    if (ix->shard_ntiles == h->n_tiles) {
+        d->df_shard.assign(ix->host.df, ix->host.df + h->n_terms);
+    } else {
+        d->df_shard.assign(h->n_terms, 0);
+        const uint64_t stride = (uint64_t)h->n_terms + 1;
+        for (uint32_t t = ix->shard_tile0; t < ix->shard_tile0 + ix->shard_ntiles; ++t) {
+            const uint32_t* sp = ix->host.seg_ptr + (uint64_t)t * stride;
+            for (uint32_t v = 0; v < h->n_terms; ++v) {
+                const uint32_t len = sp[v + 1] - sp[v];
+                if (!len) continue;
+                const uint32_t* last = ix->host.postings + ((uint64_t)sp[v + 1] - 1) * 4;
+                uint32_t zeros = (last[0] == 0) + (last[1] == 0) + (last[2] == 0) + (last[3] == 0);
+                d->df_shard[v] += len * 4 - zeros;
+            }
+        }
+    }
+    d->df_shard_ready = true;
+}
+
+}  // namespace msr
+
+// ================================================================================================ batches
+using namespace msr;
+
+struct msr_batch {
+    msr_index* ix = nullptr;
+    int nq = 0;
+    int kmax = 0;
+    int last_k = 0;
+    uint64_t nnz = 0;             // kept query entries
+    uint64_t sum_df = 0;          // sum over kept entries of df_shard(term)
+    uint32_t* d_qptr = nullptr;
+    uint32_t* d_qterm = nullptr;
+    uint32_t* d_qw = nullptr;
+    uint64_t* d_part = nullptr;   // [ntiles][nq][kmax]
+    uint64_t* d_keys = nullptr;   // [nq][kmax] local top-k keys
+    uint64_t* d_gather = nullptr; // [n_ranks][nq][kmax] (sharded search)
+    uint32_t* d_ord = nullptr;
+    uint32_t* d_su32 = nullptr;
+    float* d_sf32 = nullptr;
+    int32_t* d_n = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr;
+    bool timed = false;
+};
+
+static void batch_free(msr_batch* b) {
+    if (!b) return;
+    if (b->ix && b->ix->dev) (void)hipSetDevice(b->ix->dev->device);
+    void* ptrs[] = {b->d_qptr, b->d_qterm, b->d_qw, b->d_part, b->d_keys, b->d_gather, b->d_ord, b->d_su32, b->d_sf32, b->d_n};
+    for (void* p : ptrs)
+        if (p) (void)hipFree(p);
+    if (b->ev0) (void)hipEventDestroy(b->ev0);
+    if (b->ev1) (void)hipEventDestroy(b->ev1);
+    if (b->ev2) (void)hipEventDestroy(b->ev2);
+    delete b;
+}
+
+extern "C" {
+
+int msr_batch_create(msr_index* ix, const int64_t* q_ptr, const int32_t* q_term, const int32_t* q_w, int nq, int kmax,
+                     uint32_t flags, msr_batch** out) {
+    if (!out) {
+        set_error("msr_batch_create: null output");
+        return MSR_E_INVAL;
+    }
+    *out = nullptr;
+    if (!ix || nq < 0 || !q_ptr) {
+        set_error("msr_batch_create: bad argument");
+        return MSR_E_INVAL;
+    }
+    if (!ix->dev) {
+        set_error("index handle has no HIP device bound (opened with device < 0); there is no CPU scoring path");
+        return MSR_E_NODEVICE;
+    }
+    if (kmax < 1 || kmax > MSR_KMAX) {
+        set_error("k must be in [1, %d] (got %d)", MSR_KMAX, kmax);
+        return MSR_E_RANGE;
+    }
+    const IndexHeader* h = ix->host.h;
+    DeviceIndex* d = ix->dev;
+    compute_df_shard(ix);
+
+    // ---- host-side query normalisation (what pyserini does before handing the query to Lucene):
+    // OOV (term < 0) and non-positive weights vanish, terms present in every doc are dropped when asked,
+    // and the worst-case score must fit the u32 accumulators.
+    std::vector<uint32_t> qptr((size_t)nq + 1, 0), qterm, qw;
+    const int64_t total_in = q_ptr[nq];
+    if (total_in < 0 || (total_in && (!q_term || !q_w))) {
+        set_error("msr_batch_create: bad CSR arrays");
+        return MSR_E_INVAL;
+    }
+    qterm.reserve((size_t)total_in);
+    qw.reserve((size_t)total_in);
+    uint64_t sum_df = 0;
+    for (int i = 0; i < nq; ++i) {
+        if (q_ptr[i + 1] < q_ptr[i] || q_ptr[i + 1] > total_in) {
+            set_error("q_ptr is not monotone at query %d", i);
+            return MSR_E_INVAL;
+        }
+        uint64_t bound = 0;
+        for (int64_t e = q_ptr[i]; e < q_ptr[i + 1]; ++e) {
+            const int32_t t = q_term[e];
+            const int32_t w = q_w[e];
+            if (t < 0 || w <= 0) continue;
+            if ((uint32_t)t >= h->n_terms) {
+                set_error("query %d: term id %d is outside the dictionary (%u terms)", i, t, h->n_terms);
+                return MSR_E_RANGE;
+            }
+            if ((flags & MSR_F_DROP_DF_EQ_N) && ix->host.df[t] == h->n_docs) continue;
+            if (ix->host.df[t] == 0) continue;
+            bound += (uint64_t)w * ix->host.maxw[t];
+            qterm.push_back((uint32_t)t);
+            qw.push_back((uint32_t)w);
+            sum_df += d->df_shard[t];
+        }
+        if (bound > 0xFFFFFFFFull) {
+            set_error("query %d: worst-case score %llu exceeds the exact u32 range", i, (unsigned long long)bound);
+            return MSR_E_OVERFLOW;
+        }
+        if (qterm.size() > 0xFFFFFFF0ull) {
+            set_error("query batch too large");
+            return MSR_E_RANGE;
+        }
+        qptr[i + 1] = (uint32_t)qterm.size();
+    }
+
+    msr_batch* b = new (std::nothrow) msr_batch;
+    if (!b) {
+        set_error("out of host memory");
+        return MSR_E_NOMEM;
+    }
+    b->ix = ix;
+    b->nq = nq;
+    b->kmax = kmax;
+    b->nnz = qterm.size();
+    b->sum_df = sum_df;
+    auto fail = [&](int rc) {
+        batch_free(b);
+        return rc;
+    };
+    if (hipSetDevice(d->device) != hipSuccess) {
+        set_error("hipSetDevice failed");
+        return fail(MSR_E_HIP);
+    }
+    const size_t nqk = std::max<size_t>((size_t)nq * kmax, 1);
+    const size_t ntiles = std::max<uint32_t>(ix->shard_ntiles, 1);
+    bool ok = hipMalloc(&b->d_qptr, ((size_t)nq + 1) * 4) == hipSuccess &&
+              hipMalloc(&b->d_qterm, std::max<size_t>(qterm.size(), 1) * 4) == hipSuccess &&
+              hipMalloc(&b->d_qw, std::max<size_t>(qw.size(), 1) * 4) == hipSuccess &&
+              hipMalloc(&b->d_part, ntiles * nqk * 8) == hipSuccess && hipMalloc(&b->d_keys, nqk * 8) == hipSuccess &&
+              hipMalloc(&b->d_ord, nqk * 4) == hipSuccess && hipMalloc(&b->d_su32, nqk * 4) == hipSuccess &&
+              hipMalloc(&b->d_sf32, nqk * 4) == hipSuccess &&
+              hipMalloc(&b->d_n, std::max<size_t>(nq, 1) * 4) == hipSuccess;
+    if (!ok) {
+        set_error("hipMalloc for the query batch failed (%d queries, kmax %d, %zu tiles)", nq, kmax, ntiles);
+        return fail(MSR_E_NOMEM);
+    }
+    ok = hipMemcpy(b->d_qptr, qptr.data(), ((size_t)nq + 1) * 4, hipMemcpyHostToDevice) == hipSuccess &&
+         (qterm.empty() || (hipMemcpy(b->d_qterm, qterm.data(), qterm.size() * 4, hipMemcpyHostToDevice) == hipSuccess &&
+                            hipMemcpy(b->d_qw, qw.data(), qw.size() * 4, hipMemcpyHostToDevice) == hipSuccess));
+    ok = ok && hipEventCreate(&b->ev0) == hipSuccess && hipEventCreate(&b->ev1) == hipSuccess &&
+         hipEventCreate(&b->ev2) == hipSuccess;
+    if (!ok) {
+        set_error("upload of the query batch failed");
+        return fail(MSR_E_HIP);
+    }
+    *out = b;
+    return MSR_OK;
+}
+
+static int batch_search_local(msr_batch* b, int k, bool final_arrays) {
+    msr_index* ix = b->ix;
+    DeviceIndex* d = ix->dev;
+    const IndexHeader* h = ix->host.h;
+    HIP_TRY(hipSetDevice(d->device));
+    HIP_TRY(hipEventRecord(b->ev0, d->stream));
+    ScoreArgs sa;
+    sa.seg_ptr = d->d_seg_ptr;
+    sa.postings = d->d_postings;
+    sa.q_ptr = b->d_qptr;
+    sa.q_term = b->d_qterm;
+    sa.q_w = b->d_qw;
+    sa.part = b->d_part;
+    sa.n_docs = h->n_docs;
+    sa.vec_base = d->vec_base;
+    sa.n_terms = h->n_terms;
+    sa.tile0 = ix->shard_tile0;
+    sa.nq = (uint32_t)b->nq;
+    sa.k = (uint32_t)k;
+    int rc = launch_score(d->stream, h->tile_docs, ix->shard_ntiles, sa);
+    if (rc != MSR_OK) return rc;
+    HIP_TRY(hipEventRecord(b->ev1, d->stream));
+    MergeArgs ma;
+    ma.lists = b->d_part;
+    ma.list_stride = (uint64_t)b->nq * k;
+    ma.n_lists = ix->shard_ntiles;
+    ma.nq = (uint32_t)b->nq;
+    ma.k = (uint32_t)k;
+    ma.out_keys = b->d_keys;
+    ma.out_ord = final_arrays ? b->d_ord : nullptr;
+    ma.out_score_u32 = b->d_su32;
+    ma.out_score = b->d_sf32;
+    ma.out_n = b->d_n;
+    rc = launch_merge(d->stream, ma);
+    if (rc != MSR_OK) return rc;
+    HIP_TRY(hipEventRecord(b->ev2, d->stream));
+    b->last_k = k;
+    b->timed = true;
+    return MSR_OK;
+}
+
+int msr_batch_search(msr_batch* b, int k) {
+    if (!b) {
+        set_error("msr_batch_search: null batch");
+        return MSR_E_INVAL;
+    }
+    if (k < 1 || k > b->kmax) {
+        set_error("k=%d outside [1, kmax=%d]", k, b->kmax);
+        return MSR_E_RANGE;
+    }
+    return batch_search_local(b, k, true);
+}
+
+int msr_batch_sync(msr_batch* b) {
+    if (!b) {
+        set_error("msr_batch_sync: null batch");
+        return MSR_E_INVAL;
+    }
+    HIP_TRY(hipSetDevice(b->ix->dev->device));
+    HIP_TRY(hipStreamSynchronize(b->ix->dev->stream));
+    return MSR_OK;
+}
+
+int msr_batch_fetch(msr_batch* b, uint32_t* out_doc_ord, float* out_score, uint32_t* out_score_u32, int32_t* out_n) {
+    if (!b || b->last_k == 0) {
+        set_error("msr_batch_fetch: no search has run on this batch");
+        return MSR_E_INVAL;
+    }
+    int rc = msr_batch_sync(b);
+    if (rc != MSR_OK) return rc;
+    const size_t n = (size_t)b->nq * b->last_k;
+    if (n) {
+        if (out_doc_ord) HIP_TRY(hipMemcpy(out_doc_ord, b->d_ord, n * 4, hipMemcpyDeviceToHost));
+        if (out_score) HIP_TRY(hipMemcpy(out_score, b->d_sf32, n * 4, hipMemcpyDeviceToHost));
+        if (out_score_u32) HIP_TRY(hipMemcpy(out_score_u32, b->d_su32, n * 4, hipMemcpyDeviceToHost));
+    }
+    if (out_n && b->nq) HIP_TRY(hipMemcpy(out_n, b->d_n, (size_t)b->nq * 4, hipMemcpyDeviceToHost));
+    return MSR_OK;
+}
+
+int msr_batch_kernel_ms(msr_batch* b, float* score_ms, float* merge_ms) {
+    if (!b || !b->timed) {
+        set_error("msr_batch_kernel_ms: no search has run on this batch");
+        return MSR_E_INVAL;
+    }
+    int rc = msr_batch_sync(b);
+    if (rc != MSR_OK) return rc;
+    float a = 0, c = 0;
+    HIP_TRY(hipEventElapsedTime(&a, b->ev0, b->ev1));
+    HIP_TRY(hipEventElapsedTime(&c, b->ev1, b->ev2));
+    if (score_ms) *score_ms = a;
+    if (merge_ms) *merge_ms = c;
+    return MSR_OK;
+}
+
+int msr_batch_algo_bytes(const msr_batch* b, int k, uint64_t* bytes, uint64_t* postings) {
+    if (!b || k < 1) {
+        set_error("msr_batch_algo_bytes: bad argument");
+        return MSR_E_INVAL;
+    }
+    // bytes(q) = sum_t df(t)*(4+2) + |q|*12 + k*8
+    if (bytes) *bytes = b->sum_df * 6 + b->nnz * 12 + (uint64_t)b->nq * k * 8;
+    if (postings) *postings = b->sum_df;
+    return MSR_OK;
+}
+
+void msr_batch_destroy(msr_batch* b) { batch_free(b); }
+
+int msr_search_csr(msr_index* ix, const int64_t* q_ptr, const int32_t* q_term, const int32_t* q_w, int nq, int k,
+                   uint32_t flags, uint32_t* out_doc_ord, float* out_score, uint32_t* out_score_u32, int32_t* out_n) {
+    msr_batch* b = nullptr;
+    int rc = msr_batch_create(ix, q_ptr, q_term, q_w, nq, k, flags, &b);
+    if (rc != MSR_OK) return rc;
+    rc = msr_batch_search(b, k);
+    if (rc == MSR_OK) rc = msr_batch_fetch(b, out_doc_ord, out_score, out_score_u32, out_n);
+    msr_batch_destroy(b);
+    return rc;
+}
+
+// ------------------------------------------------------------------------------------------------ merge of host lists
+int msr_merge_lists(msr_index* ix, int n_lists, int nq, int k, const uint32_t* doc_ord, const uint32_t* score_u32,
+                    const int32_t* n, uint32_t* out_doc_ord, float* out_score, uint32_t* out_score_u32, int32_t* out_n) {
+    if (!ix || n_lists < 1 || nq < 0 || !doc_ord || !score_u32 || !n) {
+        set_error("msr_merge_lists: bad argument");
+        return MSR_E_INVAL;
+    }
+    if (!ix->dev) {
+        set_error("index handle has no HIP device bound; there is no CPU merge path");
+        return MSR_E_NODEVICE;
+    }
+    if (k < 1 || k > MSR_KMAX) {
+        set_error("k must be in [1, %d]", MSR_KMAX);
+        return MSR_E_RANGE;
+    }
+    DeviceIndex* d = ix->dev;
+    HIP_TRY(hipSetDevice(d->device));
+    const size_t per = (size_t)nq * k;
+    std::vector<uint64_t> keys((size_t)n_lists * per, 0);
+    for (int l = 0; l < n_lists; ++l)
+        for (int q = 0; q < nq; ++q) {
+            const int cnt = std::min(std::max(n[(size_t)l * nq + q], 0), k);
+            for (int j = 0; j < cnt; ++j) {
+                const size_t o = (size_t)l * per + (size_t)q * k + j;
+                if (score_u32[o]) keys[o] = ((uint64_t)score_u32[o] << 32) | (uint64_t)(0xFFFFFFFFu - doc_ord[o]);
+            }
+        }
+    uint64_t* d_lists = nullptr;
+    uint32_t *d_ord = nullptr, *d_su = nullptr;
+    float* d_sf = nullptr;
+    int32_t* d_n = nullptr;
+    const size_t perz = std::max<size_t>(per, 1);
+    int rc = MSR_OK;
+    bool ok = hipMalloc(&d_lists, std::max<size_t>(keys.size(), 1) * 8) == hipSuccess &&
+              hipMalloc(&d_ord, perz * 4) == hipSuccess && hipMalloc(&d_su, perz * 4) == hipSuccess &&
+              hipMalloc(&d_sf, perz * 4) == hipSuccess && hipMalloc(&d_n, std::max<size_t>(nq, 1) * 4) == hipSuccess;
+    if (!ok) {
+        set_error("hipMalloc failed in msr_merge_lists");
+        rc = MSR_E_NOMEM;
+    }
+    if (rc == MSR_OK && !keys.empty() &&
+        hipMemcpy(d_lists, keys.data(), keys.size() * 8, hipMemcpyHostToDevice) != hipSuccess) {
+        set_error("upload failed in msr_merge_lists");
+        rc = MSR_E_HIP;
+    }
+    if (rc == MSR_OK) {
+        MergeArgs ma;
+        ma.lists = d_lists;
+        ma.list_stride = per;
+        ma.n_lists = (uint32_t)n_lists;
+        ma.nq = (uint32_t)nq;
+        ma.k = (uint32_t)k;
+        ma.out_keys = nullptr;
+        ma.out_ord = d_ord;
+        ma.out_score_u32 = d_su;
+        ma.out_score = d_sf;
+        ma.out_n = d_n;
+        rc = launch_merge(d->stream, ma);
+    }
+    if (rc == MSR_OK && hipStreamSynchronize(d->stream) != hipSuccess) {
+        set_error("merge kernel failed");
+        rc = MSR_E_HIP;
+    }
+    if (rc == MSR_OK && per) {
+        bool c = (!out_doc_ord || hipMemcpy(out_doc_ord, d_ord, per * 4, hipMemcpyDeviceToHost) == hipSuccess) &&
+                 (!out_score || hipMemcpy(out_score, d_sf, per * 4, hipMemcpyDeviceToHost) == hipSuccess) &&
+                 (!out_score_u32 || hipMemcpy(out_score_u32, d_su, per * 4, hipMemcpyDeviceToHost) == hipSuccess) &&
+                 (!out_n || hipMemcpy(out_n, d_n, (size_t)nq * 4, hipMemcpyDeviceToHost) == hipSuccess);
+        if (!c) {
+            set_error("download failed in msr_merge_lists");
+            rc = MSR_E_HIP;
+        }
+    }
+    void* ptrs[] = {d_lists, d_ord, d_su, d_sf, d_n};
+    for (void* p : ptrs)
+        if (p) (void)hipFree(p);
+    return rc;
+}
+
+// ------------------------------------------------------------------------------------------------ RCCL exchange
+int msr_comm_unique_id(char id[MSR_COMM_ID_BYTES]) {
+    static_assert(sizeof(ncclUniqueId) <= MSR_COMM_ID_BYTES, "id buffer too small");
+    if (!id) {
+        set_error("msr_comm_unique_id: null buffer");
+        return MSR_E_INVAL;
+    }
+    ncclUniqueId u;
+    ncclResult_t r = ncclGetUniqueId(&u);
+    if (r != ncclSuccess) {
+        set_error("ncclGetUniqueId failed: %s", ncclGetErrorString(r));
+        return MSR_E_COMM;
+    }
+    memset(id, 0, MSR_COMM_ID_BYTES);
+    memcpy(id, &u, sizeof(u));
+    return MSR_OK;
+}
+
+int msr_comm_init(msr_index* ix, int n_ranks, int rank, const char id[MSR_COMM_ID_BYTES]) {
+    if (!ix || !id || n_ranks < 1 || rank < 0 || rank >= n_ranks) {
+        set_error("msr_comm_init: bad argument");
+        return MSR_E_INVAL;
+    }
+    if (!ix->dev) {
+        set_error("index handle has no HIP device bound");
+        return MSR_E_NODEVICE;
+    }
+    DeviceIndex* d = ix->dev;
+    HIP_TRY(hipSetDevice(d->device));
+    if (d->comm) {
+        ncclCommDestroy(d->comm);
+        d->comm = nullptr;
+    }
+    ncclUniqueId u;
+    memcpy(&u, id, sizeof(u));
+    ncclResult_t r = ncclCommInitRank(&d->comm, n_ranks, u, rank);
+    if (r != ncclSuccess) {
+        d->comm = nullptr;
+        set_error("ncclCommInitRank(%d of %d) failed: %s", rank, n_ranks, ncclGetErrorString(r));
+        return MSR_E_COMM;
+    }
+    d->n_ranks = n_ranks;
+    d->rank = rank;
+    return MSR_OK;
+}
+
+int msr_comm_destroy(msr_index* ix) {
+    if (!ix || !ix->dev) return MSR_OK;
+    if (ix->dev->comm) {
+        (void)hipSetDevice(ix->dev->device);
+        ncclCommDestroy(ix->dev->comm);
+        ix->dev->comm = nullptr;
+    }
+    ix->dev->n_ranks = 1;
+    ix->dev->rank = 0;
+    return MSR_OK;
+}
+
+int msr_batch_search_sharded(msr_batch* b, int k) {
+    if (!b) {
+        set_error("msr_batch_search_sharded: null batch");
+        return MSR_E_INVAL;
+    }
+    if (k < 1 || k > b->kmax) {
+        set_error("k=%d outside [1, kmax=%d]", k, b->kmax);
+        return MSR_E_RANGE;
+    }
+    DeviceIndex* d = b->ix->dev;
+    if (!d->comm) {
+        set_error("msr_batch_search_sharded: call msr_comm_init first");
+        return MSR_E_COMM;
+    }
+    HIP_TRY(hipSetDevice(d->device));
+    const size_t per = std::max<size_t>((size_t)b->nq * b->kmax, 1);
+    if (!b->d_gather) {
+        if (hipMalloc(&b->d_gather, per * 8 * d->n_ranks) != hipSuccess) {
+            set_error("hipMalloc of the all-gather buffer failed");
+            return MSR_E_NOMEM;
+        }
+    }
+    int rc = batch_search_local(b, k, false);  // per-shard exact top-k keys in d_keys ([nq][k])
+    if (rc != MSR_OK) return rc;
+    const size_t cnt = (size_t)b->nq * k;
+    if (cnt) {
+        ncclResult_t r = ncclAllGather(b->d_keys, b->d_gather, cnt, ncclUint64, d->comm, d->stream);
+        if (r != ncclSuccess) {
+            set_error("ncclAllGather failed: %s", ncclGetErrorString(r));
+            return MSR_E_COMM;
+        }
+    }
+    MergeArgs ma;
+    ma.lists = b->d_gather;
+    ma.list_stride = cnt;
+    ma.n_lists = (uint32_t)d->n_ranks;
+    ma.nq = (uint32_t)b->nq;
+    ma.k = (uint32_t)k;
+    ma.out_keys = nullptr;
+    ma.out_ord = b->d_ord;
+    ma.out_score_u32 = b->d_su32;
+    ma.out_score = b->d_sf32;
+    ma.out_n = b->d_n;
+    rc = launch_merge(d->stream, ma);
+    if (rc != MSR_OK) return rc;
+    HIP_TRY(hipEventRecord(b->ev2, d->stream));
+    return MSR_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,118 @@
+// Internal declarations shared by the host-side indexer and the HIP search path. Not part of the C-ABI.
+#pragma once
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <functional>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../../include/msr.h"
+
+namespace msr {
+
+// ---------------------------------------------------------------------------------------------
+// On-disk / in-HBM index layout ("tile-major" inverted index)
+//
+//   docs are numbered by ORDINAL = rank of the external doc-id string in bytewise ascending order
+//   (tie rule T1 for free), and cut into tiles of `tile_docs` consecutive ordinals. For every
+//   (tile, term) pair the postings of that term that fall into that tile form one SEGMENT:
+//
+//     posting  = u32   (weight << 16) | (ordinal - tile*tile_docs)      weight in [1, 65535]
+//     segment  = postings sorted by ordinal, zero-padded to a multiple of 4 (one 16-byte "vec")
+//     seg_ptr  = u32[n_tiles][n_terms+1]  first vec of each segment (absolute vec index)
+//
+//   Segments of one tile are contiguous (term-major inside the tile), so one tile's slice of the
+//   index is a contiguous byte range: that is what a doc-range shard uploads, and what the
+//   workgroups scoring that tile keep hot in their XCD's L2.
+// ---------------------------------------------------------------------------------------------
+
+enum Section : int {
+    SEC_TERM_OFF = 0,   // u64[n_terms+1]   byte offsets into SEC_TERM_STR (NUL-terminated strings)
+    SEC_TERM_STR,       // bytes
+    SEC_TERM_SORTED,    // u32[n_terms]     term ids in bytewise ascending order of their strings
+    SEC_DF,             // u32[n_terms]     document frequency
+    SEC_MAXW,           // u32[n_terms]     largest stored weight of the term
+    SEC_DOC_OFF,        // u64[n_docs+1]    byte offsets into SEC_DOC_STR (NUL-terminated), by ordinal
+    SEC_DOC_STR,        // bytes
+    SEC_SEG_PTR,        // u32[n_tiles*(n_terms+1)]
+    SEC_POSTINGS,       // u32[n_vecs*4]
+    SEC_COUNT
+};
+
+struct IndexHeader {
+    char magic[8];  // "MSRIDX01"
+    uint32_t version;
+    uint32_t tile_docs;
+    uint64_t n_docs;
+    uint64_t n_postings;
+    uint64_t n_vecs;
+    uint32_t n_terms;
+    uint32_t n_tiles;
+    uint32_t max_weight;
+    uint32_t flags;
+    uint64_t off[SEC_COUNT];   // byte offset of each section in the file
+    uint64_t size[SEC_COUNT];  // byte size of each section
+    uint64_t file_size;
+    uint64_t reserved[3];
+};
+
+constexpr uint32_t kIndexVersion = 1;
+constexpr uint32_t kDefaultTileDocs = 32768;
+constexpr uint32_t kMaxWeight = 65535;
+
+// thread-local error message (msr_last_error)
+void set_error(const char* fmt, ...) __attribute__((format(printf, 1, 2)));
+const char* last_error();
+
+// run fn(thread_idx) on n_threads threads (n_threads <= 1 runs inline)
+void parallel_run(int n_threads, const std::function<void(int)>& fn);
+int clamp_threads(int threads);
+
+// Host side of an opened index (mmap of the file). The device side lives in msr_device.hip.
+struct HostIndex {
+    int fd = -1;
+    const uint8_t* base = nullptr;
+    size_t bytes = 0;
+    const IndexHeader* h = nullptr;
+    const uint64_t* term_off = nullptr;
+    const char* term_str = nullptr;
+    const uint32_t* term_sorted = nullptr;
+    const uint32_t* df = nullptr;
+    const uint32_t* maxw = nullptr;
+    const uint64_t* doc_off = nullptr;
+    const char* doc_str = nullptr;
+    const uint32_t* seg_ptr = nullptr;
+    const uint32_t* postings = nullptr;
+
+    int open(const char* path);  // MSR_OK or error (message set)
+    void close();
+    int32_t lookup(const char* tok) const;  // -1 if absent
+};
+
+struct DeviceIndex;  // defined in msr_device.hip
+
+}  // namespace msr
+
+// The opaque C handle: host mmap + (optional) device residency.
+struct msr_index {
+    msr::HostIndex host;
+    msr::DeviceIndex* dev = nullptr;  // null when opened with device < 0
+    int device = -1;
+    uint32_t shard_tile0 = 0;
+    uint32_t shard_ntiles = 0;
+};
+
+namespace msr {
+
+// implemented in msr_device.hip
+int device_attach(msr_index* ix, int device);  // upload the shard [shard_tile0, shard_tile0+shard_ntiles)
+void device_detach(msr_index* ix);
+
+int build_from_csr(const char* out_path, uint64_t n_docs, uint32_t n_terms, const uint64_t* doc_ptr,
+                   const uint32_t* term_id, const uint32_t* weight, const char* const* doc_ids,
+                   const char* const* term_strs, int threads, uint32_t tile_docs);
+
+}  // namespace msr

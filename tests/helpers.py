@@ -1,0 +1,83 @@
+"""Shared test helpers: seeded workloads, an independent reader of the index file, oracle adapters."""
+from __future__ import annotations
+
+import struct
+
+import numpy as np
+
+SECTIONS = ["term_off", "term_str", "term_sorted", "df", "maxw", "doc_off", "doc_str", "seg_ptr", "postings"]
+
+
+def read_index_file(path):
+    """Decode an MSRIDX01 file independently of libmsr.so (layout: csrc/msr_internal.h)."""
+    raw = np.fromfile(path, dtype=np.uint8)
+    b = raw.tobytes()
+    magic = b[:8]
+    assert magic == b"MSRIDX01", magic
+    version, tile_docs = struct.unpack_from("<II", b, 8)
+    n_docs, n_postings, n_vecs = struct.unpack_from("<QQQ", b, 16)
+    n_terms, n_tiles, max_weight, flags = struct.unpack_from("<IIII", b, 40)
+    off = struct.unpack_from("<9Q", b, 56)
+    size = struct.unpack_from("<9Q", b, 56 + 72)
+    (file_size,) = struct.unpack_from("<Q", b, 56 + 144)
+    assert file_size == len(b)
+    sec = {name: b[off[i] : off[i] + size[i]] for i, name in enumerate(SECTIONS)}
+    term_off = np.frombuffer(sec["term_off"], dtype=np.uint64)
+    doc_off = np.frombuffer(sec["doc_off"], dtype=np.uint64)
+    terms = [sec["term_str"][int(term_off[i]) : int(term_off[i + 1]) - 1].decode("utf-8", "surrogateescape")
+             for i in range(n_terms)]
+    docs = [sec["doc_str"][int(doc_off[i]) : int(doc_off[i + 1]) - 1].decode("utf-8", "surrogateescape")
+            for i in range(n_docs)]
+    seg_ptr = np.frombuffer(sec["seg_ptr"], dtype=np.uint32).reshape(n_tiles, n_terms + 1)
+    postings = np.frombuffer(sec["postings"], dtype=np.uint32)
+    return dict(version=version, tile_docs=tile_docs, n_docs=n_docs, n_postings=n_postings, n_vecs=n_vecs,
+                n_terms=n_terms, n_tiles=n_tiles, max_weight=max_weight, terms=terms, docs=docs,
+                term_sorted=np.frombuffer(sec["term_sorted"], dtype=np.uint32),
+                df=np.frombuffer(sec["df"], dtype=np.uint32), maxw=np.frombuffer(sec["maxw"], dtype=np.uint32),
+                seg_ptr=seg_ptr, postings=postings)
+
+
+def index_file_to_dense(ix):
+    """Tile-major postings -> dense [n_docs, n_terms] int64 matrix (small indexes only)."""
+    D = np.zeros((ix["n_docs"], ix["n_terms"]), dtype=np.int64)
+    for tile in range(ix["n_tiles"]):
+        for t in range(ix["n_terms"]):
+            a, b = int(ix["seg_ptr"][tile, t]) * 4, int(ix["seg_ptr"][tile, t + 1]) * 4
+            seg = ix["postings"][a:b]
+            real = seg[seg != 0]
+            # padding only at the end of a segment, ordinals ascending inside it
+            assert (seg[: len(real)] == real).all()
+            loc = (real & 0xFFFF).astype(np.int64)
+            assert (np.diff(loc) > 0).all()
+            D[tile * ix["tile_docs"] + loc, t] += (real >> 16).astype(np.int64)
+    return D
+
+
+def synth(n_docs, doc_nnz, n_queries, q_nnz, n_terms, seed):
+    import mllm_sparse_retrieval_amd as m
+
+    dp, dt, dw = m.synth_vectors(n_docs, doc_nnz, n_terms, seed=seed, threads=8)
+    qp, qt, qw = m.synth_vectors(n_queries, q_nnz, n_terms, seed=seed + 1000003, threads=8)
+    return (dp, dt, dw), (qp.astype(np.int64), qt.astype(np.int32), qw.astype(np.int32))
+
+
+def taat_oracle(docs, n_terms, doc_ids=None):
+    from oracle import taat
+
+    dp, dt, dw = docs
+    ix, order = taat.TaatIndex.from_rows_by_docid(dp, dt, dw, n_terms, doc_ids)
+    return ix, order
+
+
+def assert_same_results(got, want, k):
+    """got = (ords u32, f32 scores, u32 scores, n) from libmsr; want = (ords i64 / -1 pad, scores i64, n)."""
+    g_ord, g_f32, g_u32, g_n = got
+    w_ord, w_sc, w_n = want
+    assert (g_n == w_n).all(), np.flatnonzero(g_n != w_n)[:10]
+    mask = np.arange(k)[None, :] < w_n[:, None]
+    assert (g_ord.astype(np.int64)[mask] == w_ord[mask]).all(), "doc ordinals differ"
+    assert (g_u32.astype(np.int64)[mask] == w_sc[mask]).all(), "exact scores differ"
+    # f32 scores: |delta| <= 1e-5 (north_star); exact below 2^24
+    assert np.abs(g_f32.astype(np.float64)[mask] - w_sc.astype(np.float64)[mask]
+                  ).max(initial=0) <= np.where(w_sc.max(initial=0) < 2**24, 1e-5, np.inf)
+    assert (g_u32[~mask] == 0).all()
