@@ -1,0 +1,325 @@
+#!/usr/bin/env python3
+"""Benchmark of the sparse-search hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run, one rank per GPU)
+
+A "step" is one pass of the hot path over one batch of synthetic queries: the scoring kernel + top-k merge for every
+query of the batch, with the index and the CSR queries already resident in HBM.
+
+Headline workload (BASELINE.json metric, configs[1]): Flickr30K-shape text->image sparse search, top-10.
+  N > 1: the reference's own data parallelism (src/search.py:180-182): every rank holds the (16 MB) index and scores
+  its own queries; no data-path collective; "scaling": "weak".
+Extra object "c4_1m" (BASELINE.json configs[3], the north-star target): 1 M docs / 10 000 queries; at N > 1 the index
+  is doc-range sharded over the ranks and the per-shard top-k lists are merged after ONE RCCL all-gather (exact);
+  "scaling": "strong".
+
+rank 0 prints ONE JSON line. torch is used only as launcher plumbing (gloo barrier / max-reduce); the search path is
+ctypes -> libmsr.so -> HIP.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import tempfile
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6.3 TB/s is what a copy achieves
+
+
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+class Ranks:
+    """Launcher plumbing: rank info, barrier and max-over-ranks (gloo; the data path never touches torch)."""
+
+    def __init__(self, n_gpus):
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        self.dist = None
+        if self.world > 1:
+            import datetime
+
+            import torch.distributed as dist
+
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            dist.init_process_group("gloo", timeout=datetime.timedelta(minutes=20))
+            self.dist = dist
+        if n_gpus != self.world:
+            log(f"[bench] note: --gpus {n_gpus} but WORLD_SIZE={self.world}; using WORLD_SIZE")
+
+    def barrier(self):
+        if self.dist:
+            self.dist.barrier()
+
+    def max(self, x):
+        if not self.dist:
+            return x
+        import torch
+
+        t = torch.tensor([x], dtype=torch.float64)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def bcast_bytes(self, b, n):
+        if not self.dist:
+            return b
+        obj = [b if self.rank == 0 else None]
+        self.dist.broadcast_object_list(obj, src=0)
+        return obj[0]
+
+    def any_failed(self, failed):
+        """True on every rank if any rank reports a failure (keeps the ranks in step instead of deadlocking)."""
+        return self.max(1.0 if failed else 0.0) > 0
+
+    def close(self):
+        if self.dist:
+            self.dist.destroy_process_group()
+
+
+def device_sync():
+    """Contract: torch.cuda.synchronize() on both sides of the timed region (device-wide, covers libmsr's stream)."""
+    try:
+        import torch
+
+        if torch.cuda.is_available():
+            torch.cuda.synchronize()
+    except Exception:
+        pass
+
+
+def timed_steps(batch, k, steps, warmup, ranks, sharded=False):
+    for _ in range(warmup):
+        batch.search(k, sharded=sharded)
+    batch.sync()
+    batch.timing_reset()
+    ranks.barrier()
+    device_sync()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        batch.search(k, sharded=sharded)
+    batch.sync()
+    device_sync()
+    ranks.barrier()
+    dt = time.perf_counter() - t0
+    calls, score_ms, merge_ms = batch.timing_sum()
+    return ranks.max(dt), score_ms / max(calls, 1), merge_ms / max(calls, 1)
+
+
+def roofline(batch, k, score_ms_avg, workload_name):
+    by, postings = batch.algo_bytes(k)
+    achieved = by / (score_ms_avg * 1e-3) / 1e9 if score_ms_avg > 0 else 0.0
+    traffic = None
+    tf = os.path.join(ROOT, "profiles", "traffic.json")  # HBM bytes per launch from rocprofv3 --pmc runs
+    if os.path.exists(tf):
+        try:
+            traffic = json.load(open(tf)).get(workload_name)
+        except Exception:
+            traffic = None
+    return {"bound": "hbm", "kernel": "score_tiles", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+            "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+            "algorithmic_bytes_per_launch": by, "postings_per_launch": postings,
+            "kernel_ms": round(score_ms_avg, 4)}
+
+
+def cpu_baseline(wl, got, target_seconds, threads):
+    """The oracle's C restatement (multithreaded term-at-a-time) timed on this host on a bounded query sample, and
+    used as the checker of the GPU results on that sample. Checker only: nothing here feeds the GPU path."""
+    from oracle import taat
+
+    dp, dt, dw = wl.docs
+    qp, qt, qw = wl.queries
+    nq = len(qp) - 1
+    t0 = time.perf_counter()
+    oix, _ = taat.TaatIndex.from_rows_by_docid(dp, dt, dw, wl.n_terms)
+    build_s = time.perf_counter() - t0
+
+    def sub(a, b):
+        return (qp[a : b + 1] - qp[a]), qt[qp[a] : qp[b]], qw[qp[a] : qp[b]]
+
+    probe = min(nq, max(4 * threads, 64))
+    t0 = time.perf_counter()
+    oix.search(*sub(0, probe), wl.k, threads=threads)
+    per_q = (time.perf_counter() - t0) / probe
+    n = int(min(nq, max(probe, target_seconds / max(per_q, 1e-9))))
+    t0 = time.perf_counter()
+    w_ord, w_sc, w_n = oix.search(*sub(0, n), wl.k, threads=threads)
+    dt_s = time.perf_counter() - t0
+    g_ord, _, g_u32, g_n = got
+    mask = np.arange(wl.k)[None, :] < w_n[:, None]
+    mism = int((g_n[:n] != w_n).sum() + (g_ord[:n].astype(np.int64)[mask] != w_ord[mask]).sum()
+               + (g_u32[:n].astype(np.int64)[mask] != w_sc[mask]).sum())
+    return {"value": round(n / dt_s, 1), "unit": "queries/s", "cores": threads, "kind": "port",
+            "sample": f"first {n} of {nq} queries of the same workload, {threads} threads, exhaustive term-at-a-time "
+                      f"C restatement (oracle/oracle_taat.c); index build {build_s:.1f}s not timed",
+            "seconds": round(dt_s, 2)}, {"checked_queries": n, "mismatches": mism}
+
+
+def run_headline(args, ranks, m, wlmod):
+    seed = 1
+    t0 = time.perf_counter()
+    wl = wlmod.flickr30k_t2i(n_images=args.flickr_images, seed=seed, threads=args.host_threads)
+    if ranks.world > 1:  # every rank scores its own captions (DP over queries, src/search.py:180-182)
+        wl.queries = wlmod.planted_captions(wl.docs, wl.n_terms, 5, 8, 15, 6, seed + 1 + 100 * ranks.rank,
+                                            args.host_threads)
+    log(f"[bench r{ranks.rank}] workload {wl.name} generated in {time.perf_counter() - t0:.1f}s")
+    tmp = tempfile.mkdtemp(prefix="msr_bench_")
+    path = m.build_index_from_csr(os.path.join(tmp, f"flickr_{ranks.rank}.idx"), *wl.docs, wl.n_terms,
+                                  threads=args.host_threads, tile_docs=args.tile_docs)
+    ix = m.SparseIndex(path, device=ranks.local_rank)
+    qp, qt, qw = wl.queries
+    nq = len(qp) - 1
+    batch = ix.batch(qp, qt, qw, wl.k)
+    wall, score_ms, merge_ms = timed_steps(batch, wl.k, args.steps, args.warmup, ranks)
+    out = {
+        "metric": "queries/sec, Flickr30K-shape text->image sparse search (top-10), MI355X",
+        "value": round(ranks.world * nq * args.steps / wall, 1),
+        "unit": "queries/s",
+        "n_gpus": ranks.world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(wall / args.steps * 1e3, 4),
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "u32",
+        "data": "synthetic",
+        "config": {"workload": wl.description, "queries_per_step_per_gpu": nq, "k": wl.k,
+                   "tile_docs": ix.tile_docs, "n_tiles": ix.n_tiles,
+                   "parallelism": "1 GPU" if ranks.world == 1 else f"dp{ranks.world} over queries, index replicated"},
+    }
+    if ranks.rank == 0:
+        out["roofline"] = roofline(batch, wl.k, score_ms, wl.name)
+        out["roofline"]["merge_kernel_ms"] = round(merge_ms, 4)
+        got = batch.fetch()
+        # Recall@1/5/10 of the GPU results (qrels: caption j <-> image j // 5)
+        doc_int = np.array([int(ix.docid(o)) for o in range(ix.n_docs)], dtype=np.int64)
+        ranked = np.where(np.arange(wl.k)[None, :] < got[3][:, None], doc_int[np.minimum(got[0], ix.n_docs - 1)], -1)
+        target = (np.arange(nq) // 5)[:, None]
+        out["recall"] = {f"R@{k}": round(float((ranked[:, :k] == target).any(axis=1).mean()), 5) for k in (1, 5, 10)}
+        if ranks.world == 1 and not args.no_cpu:
+            cb, par = cpu_baseline(wl, got, args.cpu_seconds, args.cpu_threads)
+            out["cpu_baseline"] = cb
+            out["parity"] = par
+            out["speedup_vs_cpu"] = round(out["value"] / cb["value"], 1)
+    batch.close()
+    ix.close()
+    try:
+        os.remove(path)
+        os.rmdir(tmp)
+    except OSError:
+        pass
+    return out
+
+
+def run_c4(args, ranks, m, wlmod):
+    """configs[3]: 1 M docs; doc-range shards + one RCCL all-gather of the per-shard top-k (exact)."""
+    t0 = time.perf_counter()
+    shm = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else tempfile.gettempdir()
+    path = os.path.join(shm, f"msr_c4_{os.environ.get('MASTER_PORT', 'p')}_{os.getuid()}.idx")
+    wl = None
+    err = None
+    if ranks.rank == 0:
+        try:
+            wl = wlmod.c4_1m(n_docs=args.c4_docs, n_queries=args.c4_queries, threads=args.host_threads)
+            m.build_index_from_csr(path, *wl.docs, wl.n_terms, threads=args.host_threads, tile_docs=32768)
+            log(f"[bench] c4 corpus + index in {time.perf_counter() - t0:.1f}s -> {path}")
+        except Exception as e:
+            err = e
+    if ranks.any_failed(err is not None):
+        raise RuntimeError(f"c4 corpus/index build failed on rank 0: {err}")
+    try:
+        ix = batch = None
+        sharded = ranks.world > 1
+        try:
+            qp, qt, qw = m.synth_vectors(args.c4_queries, 120, 30000, seed=4, threads=args.host_threads)
+            qp, qt, qw = qp.astype(np.int64), qt.astype(np.int32), qw.astype(np.int32)
+            ix = m.SparseIndex(path, device=ranks.local_rank, shard=ranks.rank, n_shards=ranks.world)
+        except Exception as e:
+            err = e
+        if ranks.any_failed(err is not None):
+            raise RuntimeError(f"opening the index shard failed on some rank (this rank: {err})")
+        if sharded:
+            uid = ranks.bcast_bytes(m.comm_unique_id() if ranks.rank == 0 else None, 128)
+            try:
+                ix.comm_init(ranks.world, ranks.rank, uid)
+            except Exception as e:
+                err = e
+            if ranks.any_failed(err is not None):
+                raise RuntimeError(f"RCCL communicator init failed on some rank (this rank: {err})")
+        batch = ix.batch(qp, qt, qw, 10)
+        wall, score_ms, merge_ms = timed_steps(batch, 10, args.steps, args.warmup, ranks, sharded=sharded)
+        nq = len(qp) - 1
+        out = {"workload": f"synthetic {args.c4_docs} docs x128 nnz ({ix.n_postings} postings), {nq} queries x120 nnz, "
+                           f"V=30000, top-10",
+               "value": round(nq * args.steps / wall, 1), "unit": "queries/s", "n_gpus": ranks.world,
+               "ms_per_step": round(wall / args.steps * 1e3, 3), "scaling": "strong",
+               "parallelism": "1 GPU" if not sharded else
+               f"index doc-range sharded over {ranks.world} GPUs ({ix.shard_ntiles} of {ix.n_tiles} tiles on rank 0), "
+               f"one RCCL all-gather of per-shard top-k + exact merge"}
+        if ranks.rank == 0:
+            out["roofline"] = roofline(batch, 10, score_ms, "c4_1m" if not sharded else f"c4_1m_shard{ranks.world}")
+            out["roofline"]["merge_and_exchange_ms"] = round(merge_ms, 4)
+            if ranks.world == 1 and not args.no_cpu:
+                cb, par = cpu_baseline(wl, batch.fetch(), args.cpu_seconds, args.cpu_threads)
+                out["cpu_baseline"] = cb
+                out["parity"] = par
+                out["speedup_vs_cpu"] = round(out["value"] / cb["value"], 1)
+        batch.close()
+        if sharded:
+            ix.comm_destroy()
+        ix.close()
+    finally:
+        ranks.barrier()
+        if ranks.rank == 0:
+            try:
+                os.remove(path)
+            except OSError:
+                pass
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--flickr-images", type=int, default=31014)
+    ap.add_argument("--tile-docs", type=int, default=0)
+    ap.add_argument("--c4-docs", type=int, default=1_000_000)
+    ap.add_argument("--c4-queries", type=int, default=10_000)
+    ap.add_argument("--no-c4", action="store_true", help="skip the 1 M-doc extra object")
+    ap.add_argument("--only-c4", action="store_true", help="(profiling) run only the 1 M-doc workload")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline / parity sample")
+    ap.add_argument("--cpu-seconds", type=float, default=10.0)
+    ap.add_argument("--cpu-threads", type=int, default=min(16, os.cpu_count() or 1))
+    ap.add_argument("--host-threads", type=int, default=min(16, os.cpu_count() or 1))
+    args = ap.parse_args()
+
+    ranks = Ranks(args.gpus)
+    import mllm_sparse_retrieval_amd as m  # raises if libmsr.so is missing: there is no fallback scorer
+    from mllm_sparse_retrieval_amd import workloads as wlmod
+
+    out = {}
+    if not args.only_c4:
+        out = run_headline(args, ranks, m, wlmod)
+    if not args.no_c4:
+        try:
+            c4 = run_c4(args, ranks, m, wlmod)
+        except Exception as e:  # the extra object must never take the headline line down
+            c4 = {"error": f"{type(e).__name__}: {e}"}
+            log(f"[bench r{ranks.rank}] c4_1m failed: {c4['error']}")
+        out["c4_1m"] = c4
+    if ranks.rank == 0:
+        print(json.dumps(out), flush=True)
+    ranks.close()
+
+
+if __name__ == "__main__":
+    main()

@@ -116,6 +116,10 @@ int msr_batch_fetch(msr_batch* b, uint32_t* out_doc_ord, float* out_score, uint3
                     int32_t* out_n); /* syncs, then copies the last search's results ([nq][k]) */
 /* HIP-event durations of the last msr_batch_search on its own stream (ms): the scoring kernel and the merge. */
 int msr_batch_kernel_ms(msr_batch* b, float* score_ms, float* merge_ms);
+/* Sums over every msr_batch_search call since the last reset (each call records its own HIP events on the
+ * index's stream), so a whole timed region can be priced without a host sync per call. */
+int msr_batch_timing_reset(msr_batch* b);
+int msr_batch_timing_sum(msr_batch* b, int* n_calls, float* score_ms, float* merge_ms);
 /* Algorithmic bytes of one search of this batch, SURVEY.md §8d:
  * sum over queries of  sum_t df(t)*(4+2) + |q|*12 + k*8  (df restricted to this handle's shard). */
 int msr_batch_algo_bytes(const msr_batch* b, int k, uint64_t* bytes, uint64_t* postings);

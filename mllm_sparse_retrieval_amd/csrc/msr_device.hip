@@ -614,7 +614,9 @@ struct msr_batch {
     uint32_t* d_su32 = nullptr;
     float* d_sf32 = nullptr;
     int32_t* d_n = nullptr;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr;  // the current call's events (borrowed from `events`)
+    std::vector<hipEvent_t> events;  // 3 per recorded search call since the last timing reset
+    size_t calls = 0;                // recorded calls
     bool timed = false;
 };
 
@@ -624,9 +626,8 @@ static void batch_free(msr_batch* b) {
     void* ptrs[] = {b->d_qptr, b->d_qterm, b->d_qw, b->d_part, b->d_keys, b->d_gather, b->d_ord, b->d_su32, b->d_sf32, b->d_n};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
-    if (b->ev0) (void)hipEventDestroy(b->ev0);
-    if (b->ev1) (void)hipEventDestroy(b->ev1);
-    if (b->ev2) (void)hipEventDestroy(b->ev2);
+    for (hipEvent_t e : b->events)
+        if (e) (void)hipEventDestroy(e);
     delete b;
 }
 
@@ -733,8 +734,6 @@ int msr_batch_create(msr_index* ix, const int64_t* q_ptr, const int32_t* q_term,
     ok = hipMemcpy(b->d_qptr, qptr.data(), ((size_t)nq + 1) * 4, hipMemcpyHostToDevice) == hipSuccess &&
          (qterm.empty() || (hipMemcpy(b->d_qterm, qterm.data(), qterm.size() * 4, hipMemcpyHostToDevice) == hipSuccess &&
                             hipMemcpy(b->d_qw, qw.data(), qw.size() * 4, hipMemcpyHostToDevice) == hipSuccess));
-    ok = ok && hipEventCreate(&b->ev0) == hipSuccess && hipEventCreate(&b->ev1) == hipSuccess &&
-         hipEventCreate(&b->ev2) == hipSuccess;
     if (!ok) {
         set_error("upload of the query batch failed");
         return fail(MSR_E_HIP);
@@ -748,6 +747,17 @@ static int batch_search_local(msr_batch* b, int k, bool final_arrays) {
     DeviceIndex* d = ix->dev;
     const IndexHeader* h = ix->host.h;
     HIP_TRY(hipSetDevice(d->device));
+    // every call gets its own event triple so that a whole timed region can be summed afterwards
+    if (b->calls >= 4096) b->calls = 0;  // bounded: callers that never reset keep only the recent calls
+    while (b->events.size() < (b->calls + 1) * 3) {
+        hipEvent_t e = nullptr;
+        HIP_TRY(hipEventCreate(&e));
+        b->events.push_back(e);
+    }
+    b->ev0 = b->events[b->calls * 3 + 0];
+    b->ev1 = b->events[b->calls * 3 + 1];
+    b->ev2 = b->events[b->calls * 3 + 2];
+    b->calls++;
     HIP_TRY(hipEventRecord(b->ev0, d->stream));
     ScoreArgs sa;
     sa.seg_ptr = d->d_seg_ptr;
@@ -835,6 +845,38 @@ int msr_batch_kernel_ms(msr_batch* b, float* score_ms, float* merge_ms) {
     HIP_TRY(hipEventElapsedTime(&c, b->ev1, b->ev2));
     if (score_ms) *score_ms = a;
     if (merge_ms) *merge_ms = c;
+    return MSR_OK;
+}
+
+int msr_batch_timing_reset(msr_batch* b) {
+    if (!b) {
+        set_error("msr_batch_timing_reset: null batch");
+        return MSR_E_INVAL;
+    }
+    int rc = msr_batch_sync(b);
+    if (rc != MSR_OK) return rc;
+    b->calls = 0;
+    return MSR_OK;
+}
+
+int msr_batch_timing_sum(msr_batch* b, int* n_calls, float* score_ms, float* merge_ms) {
+    if (!b) {
+        set_error("msr_batch_timing_sum: null batch");
+        return MSR_E_INVAL;
+    }
+    int rc = msr_batch_sync(b);
+    if (rc != MSR_OK) return rc;
+    double a = 0, c = 0;
+    for (size_t i = 0; i < b->calls; ++i) {
+        float x = 0, y = 0;
+        HIP_TRY(hipEventElapsedTime(&x, b->events[i * 3], b->events[i * 3 + 1]));
+        HIP_TRY(hipEventElapsedTime(&y, b->events[i * 3 + 1], b->events[i * 3 + 2]));
+        a += x;
+        c += y;
+    }
+    if (n_calls) *n_calls = (int)b->calls;
+    if (score_ms) *score_ms = (float)a;
+    if (merge_ms) *merge_ms = (float)c;
     return MSR_OK;
 }
 

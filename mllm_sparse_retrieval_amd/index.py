@@ -236,6 +236,15 @@ class QueryBatch:
         check(lib().msr_batch_kernel_ms(self._h, C.byref(a), C.byref(b)))
         return a.value, b.value
 
+    def timing_reset(self):
+        check(lib().msr_batch_timing_reset(self._h))
+
+    def timing_sum(self):
+        """(calls, scoring-kernel ms, merge-kernel ms) summed over every search since timing_reset()."""
+        n, a, b = C.c_int(), C.c_float(), C.c_float()
+        check(lib().msr_batch_timing_sum(self._h, C.byref(n), C.byref(a), C.byref(b)))
+        return n.value, a.value, b.value
+
     def algo_bytes(self, k):
         by, po = C.c_uint64(), C.c_uint64()
         check(lib().msr_batch_algo_bytes(self._h, int(k), C.byref(by), C.byref(po)))

@@ -57,8 +57,10 @@ class TaatIndex:
         order = np.asarray(sorted(range(n), key=lambda i: ids[i].encode("utf-8")), dtype=np.int64)
         lens = np.diff(doc_ptr)[order]
         new_ptr = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
-        gather = np.concatenate([np.arange(doc_ptr[r], doc_ptr[r + 1]) for r in order]) if n else np.zeros(0, np.int64)
-        gather = gather.astype(np.int64)
+        # entry j of the permuted CSR comes from doc_ptr[row] + (j - new_ptr[ordinal])
+        starts = np.repeat(doc_ptr[:-1][order], lens)
+        within = np.arange(int(lens.sum()), dtype=np.int64) - np.repeat(new_ptr[:-1].astype(np.int64), lens)
+        gather = starts + within
         return cls(new_ptr, np.asarray(term)[gather], np.asarray(weight)[gather], n_terms), order
 
     def search(self, q_ptr, q_term, q_w, k, drop_df_eq_n=True, threads=1):

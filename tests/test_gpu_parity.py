@@ -68,8 +68,8 @@ def test_heavy_ties_and_string_order(m, tmp_path):
         for k in (1, 10, 300, 1000):
             got = ix.search_csr(qp, qt, qw, k)
             helpers.assert_same_results(got, oix.search(qp, qt, qw, k), k)
-        ords, _, su, n = ix.search_csr(qp, qt, qw, 5)
-        got_ids = ix.docids(ords[0, : n[0]])
+        ords, _, su, cnt = ix.search_csr(qp, qt, qw, 5)
+        got_ids = ix.docids(ords[0, : cnt[0]])
     odd = sorted((str(i) for i in range(1, n, 2)), key=lambda s: s.encode())
     assert got_ids == odd[:5] and (su[0] == 14).all()
 
