@@ -111,6 +111,12 @@ def timed_steps(batch, k, steps, warmup, ranks, sharded=False):
     ranks.barrier()
     dt = time.perf_counter() - t0
     calls, score_ms, merge_ms = batch.timing_sum()
+    if os.environ.get("MSR_DEBUG_FLAGS"):
+        st = batch.debug_stamps().astype(np.float64)
+        if st.sum() > 0:
+            names = ["zero", "stage", "stream", "wait", "maxima", "cand", "rank", "-"]
+            log("[bench] wave-0 phase shares: " + ", ".join(f"{n}={v / st.sum():.3f}" for n, v in zip(names, st))
+                + f"; cycles/WG-launch total={st.sum() / max(calls + warmup, 1):.3e}")
     return ranks.max(dt), score_ms / max(calls, 1), merge_ms / max(calls, 1)
 
 
@@ -228,7 +234,7 @@ def run_c4(args, ranks, m, wlmod):
     if ranks.rank == 0:
         try:
             wl = wlmod.c4_1m(n_docs=args.c4_docs, n_queries=args.c4_queries, threads=args.host_threads)
-            m.build_index_from_csr(path, *wl.docs, wl.n_terms, threads=args.host_threads, tile_docs=32768)
+            m.build_index_from_csr(path, *wl.docs, wl.n_terms, threads=args.host_threads, tile_docs=args.c4_tile_docs)
             log(f"[bench] c4 corpus + index in {time.perf_counter() - t0:.1f}s -> {path}")
         except Exception as e:
             err = e
@@ -294,6 +300,7 @@ def main():
     ap.add_argument("--tile-docs", type=int, default=0)
     ap.add_argument("--c4-docs", type=int, default=1_000_000)
     ap.add_argument("--c4-queries", type=int, default=10_000)
+    ap.add_argument("--c4-tile-docs", type=int, default=32768)
     ap.add_argument("--no-c4", action="store_true", help="skip the 1 M-doc extra object")
     ap.add_argument("--only-c4", action="store_true", help="(profiling) run only the 1 M-doc workload")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline / parity sample")

@@ -120,6 +120,9 @@ int msr_batch_kernel_ms(msr_batch* b, float* score_ms, float* merge_ms);
  * index's stream), so a whole timed region can be priced without a host sync per call. */
 int msr_batch_timing_reset(msr_batch* b);
 int msr_batch_timing_sum(msr_batch* b, int* n_calls, float* score_ms, float* merge_ms);
+/* Diagnostic builds only (env MSR_DEBUG_FLAGS bit 3): summed s_memtime deltas of wave 0 per kernel phase
+ * {zero, stage, stream, wait, maxima, candidates, rank, -}. All zeros when the diagnostic is off. */
+int msr_batch_debug_stamps(msr_batch* b, unsigned long long out[8]);
 /* Algorithmic bytes of one search of this batch, SURVEY.md §8d:
  * sum over queries of  sum_t df(t)*(4+2) + |q|*12 + k*8  (df restricted to this handle's shard). */
 int msr_batch_algo_bytes(const msr_batch* b, int k, uint64_t* bytes, uint64_t* postings);

@@ -62,6 +62,7 @@ SYMBOLS = [
     ("msr_batch_kernel_ms", _I, [_VP, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
     ("msr_batch_timing_reset", _I, [_VP]),
     ("msr_batch_timing_sum", _I, [_VP, C.POINTER(_I), C.POINTER(C.c_float), C.POINTER(C.c_float)]),
+    ("msr_batch_debug_stamps", _I, [_VP, _VP]),
     ("msr_batch_algo_bytes", _I, [_VP, _I, C.POINTER(_U64), C.POINTER(_U64)]),
     ("msr_batch_destroy", None, [_VP]),
     ("msr_comm_unique_id", _I, [_VP]),

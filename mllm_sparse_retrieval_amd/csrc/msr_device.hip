@@ -22,6 +22,7 @@
 #include <rccl/rccl.h>
 
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <vector>
@@ -41,7 +42,6 @@ namespace msr {
 
 // ------------------------------------------------------------------------------------------------ constants
 constexpr int kQtBlock = 256;    // query terms staged in LDS per round
-constexpr int kMapCap = 4096;    // chunk -> term map entries per round
 constexpr int kCandCap = 1024;   // candidate keys per workgroup (>= MSR_KMAX)
 constexpr int kChunkVecs = 64;   // one chunk = one wave-wide uint4 load = 256 postings = 1 KiB
 static_assert(kCandCap >= MSR_KMAX, "candidate buffer must hold k keys");
@@ -84,6 +84,23 @@ __device__ __forceinline__ uint64_t wave_max_u64(uint64_t v) {
 // Rank-by-counting over `n` UNIQUE non-zero keys in LDS: key with rank r < k goes to out[r]; slots [n, k) get 0.
 template <int NT>
 __device__ __forceinline__ void rank_and_emit(const uint64_t* cand, int n, int k, uint64_t* __restrict__ out) {
+    if (n <= 64) {
+        // one wave, keys in registers, partner keys broadcast with v_readlane (no LDS round trips)
+        if (threadIdx.x < 64) {
+            const int lane = (int)threadIdx.x;
+            const uint64_t me = lane < n ? cand[lane] : 0ull;
+            const uint32_t lo = (uint32_t)me, hi = (uint32_t)(me >> 32);
+            int rank = 0;
+            for (int j = 0; j < n; ++j) {
+                const uint64_t o = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)hi, j) << 32) |
+                                   (uint32_t)__builtin_amdgcn_readlane((int)lo, j);
+                rank += o > me;
+            }
+            if (lane < n && rank < k) out[rank] = me;
+            for (int i = n + lane; i < k; i += 64) out[i] = 0;
+        }
+        return;
+    }
     for (int i = threadIdx.x; i < n; i += NT) {
         const uint64_t me = cand[i];
         int rank = 0;
@@ -115,6 +132,8 @@ struct ScoreArgs {
     uint32_t tile0;            // first (global) tile of the shard
     uint32_t nq;
     uint32_t k;
+    uint32_t dbg;              // MSR_DEBUG_FLAGS (timing ablations only; results are wrong when bits 0-2 are set)
+    unsigned long long* stamps;  // [8] summed s_memtime deltas of wave 0 per phase (dbg bit 3), else null
 };
 
 // LDS carve (bytes). The staging arrays of the streaming phase and the candidate keys of the select phase are
@@ -122,16 +141,20 @@ struct ScoreArgs {
 template <int TILE_DOCS, int NT>
 struct TileLds {
     static constexpr int kAcc = TILE_DOCS * 4;
-    static constexpr int kStage = kQtBlock * 4 * 3 + (kQtBlock + 4) * 4 + 8 * 4 + kMapCap;  // seg_start/len/w, pref, wsum, cmap
+    static constexpr int kStage = kQtBlock * 4 * 3 + (kQtBlock + 4) * 4 + 8 * 4;  // seg_start/len/w, pref, wsum
     static constexpr int kCand = kCandCap * 8;
     static constexpr int kUnion = (kStage > kCand ? kStage : kCand);
-    static constexpr int kTmax = NT * 4;
+    static constexpr int kTmax = NT * 4 + 64 * 4;  // per-thread maxima (k > waves) + per-wave maxima
     static constexpr int kTotal = kAcc + kUnion + kTmax + (int)sizeof(SelectScratch);
 };
 
-template <int TILE_DOCS, int NT, int MIN_WAVES>
+__device__ __forceinline__ uint32_t rfl(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+__device__ __forceinline__ uint32_t rdl(uint32_t v, uint32_t l) { return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)l); }
+
+template <int TILE_DOCS, int NT, int MIN_WAVES, bool DBG>
 __global__ __launch_bounds__(NT, MIN_WAVES) void score_tiles(const ScoreArgs a) {
     constexpr int NW = NT / 64;
+    constexpr int U = 8;  // 1-KiB chunk loads in flight per wave
     static_assert(TILE_DOCS % (4 * NT) == 0, "tile must be a multiple of 4*NT");
     static_assert(NT >= kQtBlock, "the staging scan uses the first 256 threads");
     using L = TileLds<TILE_DOCS, NT>;
@@ -145,15 +168,25 @@ __global__ __launch_bounds__(NT, MIN_WAVES) void score_tiles(const ScoreArgs a) 
     uint32_t* const seg_w = seg_len + kQtBlock;
     uint32_t* const pref = seg_w + kQtBlock;
     uint32_t* const wsum = pref + kQtBlock + 4;
-    uint8_t* const cmap = reinterpret_cast<uint8_t*>(wsum + 8);
     // select-phase view of the union
     uint64_t* const cand = reinterpret_cast<uint64_t*>(un);
     uint32_t* const tmax = reinterpret_cast<uint32_t*>(un + L::kUnion);
+    uint32_t* const wmax = tmax + NT;
     SelectScratch& ss = *reinterpret_cast<SelectScratch*>(un + L::kUnion + L::kTmax);
 
     const uint32_t tid = threadIdx.x;
     const uint32_t lane = tid & 63;
-    const uint32_t wave = tid >> 6;
+    const uint32_t wave = rfl(tid >> 6);        // provably wave-uniform for the compiler
+    // diagnostic build only: wave 0 stamps s_memtime at phase boundaries and adds the deltas to a side buffer
+    long long t_prev = 0;
+    auto stamp = [&](int slot) {
+        if (DBG && (a.dbg & 8u) && a.stamps && tid == 0) {
+            const long long now = clock64();
+            if (slot >= 0) atomicAdd(&a.stamps[slot], (unsigned long long)(now - t_prev));
+            t_prev = now;
+        }
+    };
+    stamp(-1);
     const uint32_t tile_l = blockIdx.x / a.nq;  // tile-major: neighbours in dispatch order share the tile
     const uint32_t q = blockIdx.x % a.nq;
     const uint32_t tile_g = a.tile0 + tile_l;
@@ -162,6 +195,20 @@ __global__ __launch_bounds__(NT, MIN_WAVES) void score_tiles(const ScoreArgs a) 
     // rounds of 4*NT accumulators that hold real docs
     const int rounds = (int)((ndocs_tile + 4 * NT - 1) / (4 * NT));
     uint4* const a4 = reinterpret_cast<uint4*>(acc);
+
+    const uint32_t qb = a.q_ptr[q], qe = a.q_ptr[q + 1];
+    const uint32_t* seg_row = a.seg_ptr + (uint64_t)tile_l * (a.n_terms + 1);
+    const uint4* post4 = reinterpret_cast<const uint4*>(a.postings);
+
+    // ---- first round's (term -> segment) lookups: two dependent global loads, issued before the zeroing so that
+    // their latency hides behind it
+    uint32_t pre_w = 0, pre_s0 = 0, pre_s1 = 0;
+    if (tid < min((uint32_t)kQtBlock, qe - qb)) {
+        const uint32_t t = a.q_term[qb + tid];
+        pre_w = a.q_w[qb + tid];
+        pre_s0 = seg_row[t];
+        pre_s1 = seg_row[t + 1];
+    }
 
     // ---- zero the accumulators that can be touched
     for (int r = 0; r < rounds; ++r) a4[r * NT + tid] = make_uint4(0, 0, 0, 0);
@@ -172,22 +219,24 @@ __global__ __launch_bounds__(NT, MIN_WAVES) void score_tiles(const ScoreArgs a) 
         ss.smax = 0;
     }
 
-    const uint32_t qb = a.q_ptr[q], qe = a.q_ptr[q + 1];
-    const uint32_t* seg_row = a.seg_ptr + (uint64_t)tile_l * (a.n_terms + 1);
-    const uint4* post4 = reinterpret_cast<const uint4*>(a.postings);
-
     for (uint32_t base = qb; base < qe; base += kQtBlock) {
         const uint32_t cnt = min((uint32_t)kQtBlock, qe - base);
-        __syncthreads();  // previous round's readers of seg_* / cmap are done; zeroing is visible
+        __syncthreads();  // previous round's readers of seg_* are done; zeroing is visible
+        stamp(0);  // zeroing (+ q_ptr fetch)
         // ---- stage the round's segments and an exclusive prefix sum of their chunk counts
         uint32_t nch = 0;
         if (tid < kQtBlock) {
             if (tid < cnt) {
-                const uint32_t t = a.q_term[base + tid];
-                const uint32_t s0 = seg_row[t], s1 = seg_row[t + 1];
+                uint32_t s0 = pre_s0, s1 = pre_s1, w = pre_w;
+                if (base != qb) {
+                    const uint32_t t = a.q_term[base + tid];
+                    s0 = seg_row[t];
+                    s1 = seg_row[t + 1];
+                    w = a.q_w[base + tid];
+                }
                 seg_start[tid] = s0 - a.vec_base;
                 seg_len[tid] = s1 - s0;
-                seg_w[tid] = a.q_w[base + tid];
+                seg_w[tid] = w;
                 nch = (s1 - s0 + kChunkVecs - 1) / kChunkVecs;
             }
             uint32_t inc = nch;  // inclusive scan inside the wave
@@ -207,104 +256,139 @@ __global__ __launch_bounds__(NT, MIN_WAVES) void score_tiles(const ScoreArgs a) 
             if (tid == kQtBlock - 1) pref[kQtBlock] = off + wsum[wave];
         }
         __syncthreads();
-        const uint32_t total = pref[kQtBlock];
-
-        for (uint32_t c0 = 0; c0 < total; c0 += kMapCap) {
-            const uint32_t cend = min(total, c0 + (uint32_t)kMapCap);
-            if (c0) __syncthreads();  // readers of the previous window are done
-            // ---- chunk -> term map for this window (parallel binary search over pref)
-            for (uint32_t c = c0 + tid; c < cend; c += NT) {
-                uint32_t lo = 0, hi = cnt;  // largest lo with pref[lo] <= c
+        // ---- the round's chunks are dealt round-robin to the waves (chunk c -> wave c % NW), which spreads the
+        // dense head terms and the one-chunk tail terms evenly. The (term, offset) of a wave's next 64 chunks is
+        // resolved lane-parallel (one binary search per lane), then broadcast chunk by chunk with v_readlane, so
+        // the inner loop is scalar control + one 16-byte load and four LDS atomics per lane.
+        const uint32_t total = rfl(pref[kQtBlock]);
+        const uint32_t c_end = total > wave ? (total - wave + NW - 1) / NW : 0u;  // chunks of this wave
+        for (uint32_t cb = 0; cb < c_end; cb += 64) {
+            const uint32_t my_i = cb + lane;
+            uint32_t m_base = 0, m_n = 0, m_w = 0;
+            if (my_i < c_end) {
+                const uint32_t my_c = wave + my_i * NW;
+                uint32_t lo = 0, hi = cnt;  // largest lo with pref[lo] <= my_c
                 while (hi - lo > 1) {
-                    uint32_t mid = (lo + hi) >> 1;
-                    if (pref[mid] <= c)
+                    const uint32_t mid = (lo + hi) >> 1;
+                    if (pref[mid] <= my_c)
                         lo = mid;
                     else
                         hi = mid;
                 }
-                cmap[c - c0] = (uint8_t)lo;
+                const uint32_t voff = (my_c - pref[lo]) * kChunkVecs;
+                m_base = seg_start[lo] + voff;
+                m_n = min((uint32_t)kChunkVecs, seg_len[lo] - voff);
+                m_w = seg_w[lo];
             }
-            __syncthreads();
-            // ---- stream the chunks: 4 loads in flight per wave, then 16 LDS atomics per lane
-            for (uint32_t c = c0 + wave; c < cend; c += 4 * NW) {
-                uint4 v[4];
-                uint32_t w[4];
+            const uint32_t nchunk = min(64u, c_end - cb);
+            for (uint32_t u0 = 0; u0 < nchunk; u0 += U) {
+                uint4 v[U];
+                uint32_t w[U], n[U];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const uint32_t cu = c + u * NW;
-                    v[u] = make_uint4(0, 0, 0, 0);
-                    w[u] = 0;
-                    if (cu < cend) {
-                        const uint32_t j = cmap[cu - c0];
-                        const uint32_t off = (cu - pref[j]) * kChunkVecs + lane;
-                        if (off < seg_len[j]) {
-                            v[u] = post4[seg_start[j] + off];
-                            w[u] = seg_w[j];
+                for (int u = 0; u < U; ++u) {
+                    const uint32_t idx = u0 + u;
+                    const uint32_t b = rdl(m_base, idx & 63);
+                    n[u] = idx < nchunk ? rdl(m_n, idx & 63) : 0u;
+                    w[u] = rdl(m_w, idx & 63);
+                    if (lane < n[u]) {
+                        if (DBG && (a.dbg & 2u)) {  // ablation: no global loads, synthetic postings
+                            const uint32_t hsh = ((cb + idx) * 64u + lane) * 2654435761u;
+                            v[u] = make_uint4((1u << 16) | (hsh >> 17), (1u << 16) | ((hsh * 31u) >> 17),
+                                              (1u << 16) | ((hsh * 131u) >> 17), (1u << 16) | ((hsh * 1031u) >> 17));
+                        } else {
+                            v[u] = post4[b + lane];
                         }
                     }
                 }
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    if (w[u]) {
+                for (int u = 0; u < U; ++u) {
+                    // lanes past the chunk's last vec hold nothing and must not touch LDS (64 lanes adding 0 to one
+                    // accumulator would serialise); padding INSIDE a vec has weight 0 and a lane-distinct ordinal
+                    if (lane < n[u]) {
                         const uint32_t p[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+                        if (DBG && (a.dbg & 1u)) {  // ablation: no LDS atomics (keep the loads alive)
+                            if ((p[0] ^ p[1] ^ p[2] ^ p[3]) == 0xDEADBEEFu) atomicAdd(&acc[0], 1u);
+                        } else {
 #pragma unroll
-                        for (int e = 0; e < 4; ++e)
-                            if (p[e]) atomicAdd(&acc[p[e] & 0xFFFFu], (p[e] >> 16) * w[u]);
+                            for (int e = 0; e < 4; ++e)
+                                atomicAdd(&acc[DBG ? (p[e] & 0xFFFFu) % TILE_DOCS : (p[e] & 0xFFFFu)],
+                                          __umul24(p[e] >> 16, w[u]));
+                        }
                     }
                 }
             }
         }
     }
+    stamp(2);  // wave 0's own streaming
     __syncthreads();  // accumulation complete; the staging view of the union is dead from here on
+    stamp(3);  // waiting for the slowest wave
 
     // =============================================================== exact top-k of this tile
     // Thread `tid` owns vec r*NT + tid of the accumulators in round r (conflict-free ds_read_b128); the
     // accumulators are re-read from LDS in every pass instead of being held in registers.
     uint64_t* out = a.part + ((uint64_t)tile_l * a.nq + q) * a.k;
     const int k = (int)a.k;
+    if (DBG && (a.dbg & 4u)) {  // ablation: no select phase
+        for (int i = tid; i < k; i += NT) out[i] = 0;
+        return;
+    }
 
     uint32_t mymax = 0;
     for (int r = 0; r < rounds; ++r) {
         const uint4 x = a4[r * NT + tid];
         mymax = max(max(mymax, max(x.x, x.y)), max(x.z, x.w));
     }
-    tmax[tid] = mymax;
-    __syncthreads();
-
-    // ---- wave 0: tau0 = k-th largest thread maximum (a lower bound with >= k accumulators at or above it)
-    if (wave == 0) {
-        uint32_t mine[NW];
-        uint32_t m = 0;
-#pragma unroll
-        for (int i = 0; i < NW; ++i) {
-            mine[i] = tmax[i * 64 + lane];
-            m = max(m, mine[i]);
-        }
-        m = wave_max_u32(m);
-        uint32_t tau = 0;
-        if (k <= NT && m > 0) {
-            for (int bit = 31 - __clz(m); bit >= 0; --bit) {
-                const uint32_t t2 = tau | (1u << bit);
-                uint32_t c = 0;
-#pragma unroll
-                for (int i = 0; i < NW; ++i) c += mine[i] >= t2;
-                c = wave_sum_u32(c);
-                if (c >= (uint32_t)k) tau = t2;
-            }
-        }
-        if (lane == 0) {
-            ss.tau0 = max(tau, 1u);
-            ss.smax = m;
-        }
+    {
+        const uint32_t wm = wave_max_u32(mymax);
+        if (lane == 0) wmax[wave] = wm;
+        if (k > NW) tmax[tid] = mymax;
     }
     __syncthreads();
-    const uint32_t tau0 = ss.tau0;
-    const uint32_t smax = ss.smax;
+
+    // ---- tau0: a lower bound with at least k accumulators at or above it.
+    //   k <= NW : the k-th largest WAVE maximum (every wave ranks the NW maxima by counting, no further barrier)
+    //   k >  NW : the k-th largest THREAD maximum (wave 0 bisects on ballots)
+    uint32_t tau0, smax;
+    {
+        const uint32_t v = lane < (uint32_t)NW ? wmax[lane] : 0u;
+        uint32_t rank = 0, m = 0;
+#pragma unroll
+        for (int j = 0; j < NW; ++j) {
+            const uint32_t o = rdl(v, j);
+            rank += (o > v) || (o == v && (uint32_t)j < lane);
+            m = max(m, o);
+        }
+        smax = m;
+        tau0 = 1;
+        if (k <= NW) {
+            const unsigned long long mk = __ballot(lane < (uint32_t)NW && rank == (uint32_t)(k - 1));
+            tau0 = max(rdl(v, (uint32_t)(__ffsll((long long)mk) - 1) & 63u), 1u);
+        }
+    }
     if (smax == 0) {  // nothing matched in this tile
         for (int i = tid; i < k; i += NT) out[i] = 0;
         return;
     }
+    if (k > NW && k <= NT) {
+        if (wave == 0) {
+            uint32_t mine[NW];
+#pragma unroll
+            for (int i = 0; i < NW; ++i) mine[i] = tmax[i * 64 + lane];
+            uint32_t tau = 0;
+            for (int bit = 31 - __clz(smax); bit >= 0; --bit) {
+                const uint32_t t2 = tau | (1u << bit);
+                uint32_t c = 0;
+#pragma unroll
+                for (int i = 0; i < NW; ++i) c += (uint32_t)__popcll(__ballot(mine[i] >= t2));
+                if (c >= (uint32_t)k) tau = t2;
+            }
+            if (lane == 0) ss.tau0 = max(tau, 1u);
+        }
+        __syncthreads();
+        tau0 = ss.tau0;
+    }
 
+    stamp(4);  // thread / wave maxima, tau0
     // ---- candidates: accumulators >= tau0 as unique global keys (score << 32 | ~ordinal)
     if (mymax >= tau0) {
         for (int r = 0; r < rounds; ++r) {
@@ -321,6 +405,7 @@ __global__ __launch_bounds__(NT, MIN_WAVES) void score_tiles(const ScoreArgs a) 
         }
     }
     __syncthreads();
+    stamp(5);  // candidate collection
     uint32_t n_cand = ss.n_cand;
 
     if (n_cand > kCandCap) {
@@ -368,6 +453,7 @@ __global__ __launch_bounds__(NT, MIN_WAVES) void score_tiles(const ScoreArgs a) 
         n_cand = min(ss.n_cand, (uint32_t)kCandCap);  // == min(k, #positive) <= kCandCap by construction
     }
     rank_and_emit<NT>(cand, (int)n_cand, k, out);
+    stamp(6);  // ranking + output
 }
 
 // ------------------------------------------------------------------------------------------------ kernel 2
@@ -475,10 +561,17 @@ static int launch_score(hipStream_t st, uint32_t tile_docs, uint32_t ntiles, con
     switch (tile_docs) {
         // <tile docs, threads, min waves/SIMD>: 32768 -> 1 workgroup/CU (16 waves), 16384 -> 2/CU (16 waves),
         // 8192 -> 3/CU (12 waves), 4096 -> 4/CU (16 waves)
-        case 32768: hipLaunchKernelGGL((score_tiles<32768, 1024, 4>), dim3((uint32_t)blocks), dim3(1024), 0, st, a); break;
-        case 16384: hipLaunchKernelGGL((score_tiles<16384, 512, 4>), dim3((uint32_t)blocks), dim3(512), 0, st, a); break;
-        case 8192: hipLaunchKernelGGL((score_tiles<8192, 256, 3>), dim3((uint32_t)blocks), dim3(256), 0, st, a); break;
-        case 4096: hipLaunchKernelGGL((score_tiles<4096, 256, 4>), dim3((uint32_t)blocks), dim3(256), 0, st, a); break;
+#define MSR_LAUNCH(T, N, W)                                                                                   \
+    if (a.dbg)                                                                                                \
+        hipLaunchKernelGGL((score_tiles<T, N, W, true>), dim3((uint32_t)blocks), dim3(N), 0, st, a);          \
+    else                                                                                                      \
+        hipLaunchKernelGGL((score_tiles<T, N, W, false>), dim3((uint32_t)blocks), dim3(N), 0, st, a);         \
+    break;
+        case 32768: MSR_LAUNCH(32768, 1024, 4)
+        case 16384: MSR_LAUNCH(16384, 512, 4)
+        case 8192: MSR_LAUNCH(8192, 256, 3)
+        case 4096: MSR_LAUNCH(4096, 256, 4)
+#undef MSR_LAUNCH
         default:
             set_error("no kernel instance for tile_docs=%u (supported: 4096, 8192, 16384, 32768)", tile_docs);
             return MSR_E_RANGE;
@@ -583,8 +676,11 @@ static void compute_df_shard(msr_index* ix) {
             for (uint32_t v = 0; v < h->n_terms; ++v) {
                 const uint32_t len = sp[v + 1] - sp[v];
                 if (!len) continue;
-                const uint32_t* last = ix->host.postings + ((uint64_t)sp[v + 1] - 1) * 4;
-                uint32_t zeros = (last[0] == 0) + (last[1] == 0) + (last[2] == 0) + (last[3] == 0);
+                // zero padding lives in the segment's last chunk (chunk-interleaved layout, msr_internal.h)
+                const uint32_t tail = len % kChunkVecs ? len % kChunkVecs : (uint32_t)kChunkVecs;
+                const uint32_t* last = ix->host.postings + ((uint64_t)sp[v + 1] - tail) * 4;
+                uint32_t zeros = 0;
+                for (uint32_t i = 0; i < tail * 4; ++i) zeros += (last[i] >> 16) == 0;
                 d->df_shard[v] += len * 4 - zeros;
             }
         }
@@ -614,6 +710,7 @@ struct msr_batch {
     uint32_t* d_su32 = nullptr;
     float* d_sf32 = nullptr;
     int32_t* d_n = nullptr;
+    unsigned long long* d_stamps = nullptr;  // diagnostic (MSR_DEBUG_FLAGS bit 3)
     hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr;  // the current call's events (borrowed from `events`)
     std::vector<hipEvent_t> events;  // 3 per recorded search call since the last timing reset
     size_t calls = 0;                // recorded calls
@@ -623,7 +720,8 @@ struct msr_batch {
 static void batch_free(msr_batch* b) {
     if (!b) return;
     if (b->ix && b->ix->dev) (void)hipSetDevice(b->ix->dev->device);
-    void* ptrs[] = {b->d_qptr, b->d_qterm, b->d_qw, b->d_part, b->d_keys, b->d_gather, b->d_ord, b->d_su32, b->d_sf32, b->d_n};
+    void* ptrs[] = {b->d_qptr, b->d_qterm, b->d_qw, b->d_part, b->d_keys, b->d_gather, b->d_ord, b->d_su32, b->d_sf32, b->d_n,
+                    b->d_stamps};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     for (hipEvent_t e : b->events)
@@ -680,6 +778,10 @@ int msr_batch_create(msr_index* ix, const int64_t* q_ptr, const int32_t* q_term,
             if (t < 0 || w <= 0) continue;
             if ((uint32_t)t >= h->n_terms) {
                 set_error("query %d: term id %d is outside the dictionary (%u terms)", i, t, h->n_terms);
+                return MSR_E_RANGE;
+            }
+            if (w > 0xFFFFFF) {  // the kernel multiplies with v_mul_u32_u24
+                set_error("query %d: weight %d of term %d exceeds the supported maximum 16777215", i, w, t);
                 return MSR_E_RANGE;
             }
             if ((flags & MSR_F_DROP_DF_EQ_N) && ix->host.df[t] == h->n_docs) continue;
@@ -772,6 +874,18 @@ static int batch_search_local(msr_batch* b, int k, bool final_arrays) {
     sa.tile0 = ix->shard_tile0;
     sa.nq = (uint32_t)b->nq;
     sa.k = (uint32_t)k;
+    {
+        const char* dbg = getenv("MSR_DEBUG_FLAGS");
+        sa.dbg = dbg ? (uint32_t)strtoul(dbg, nullptr, 0) : 0u;
+        sa.stamps = nullptr;
+        if (sa.dbg & 8u) {
+            if (!b->d_stamps) {
+                HIP_TRY(hipMalloc(&b->d_stamps, 8 * sizeof(unsigned long long)));
+                HIP_TRY(hipMemsetAsync(b->d_stamps, 0, 8 * sizeof(unsigned long long), d->stream));
+            }
+            sa.stamps = b->d_stamps;
+        }
+    }
     int rc = launch_score(d->stream, h->tile_docs, ix->shard_ntiles, sa);
     if (rc != MSR_OK) return rc;
     HIP_TRY(hipEventRecord(b->ev1, d->stream));
@@ -877,6 +991,19 @@ int msr_batch_timing_sum(msr_batch* b, int* n_calls, float* score_ms, float* mer
     if (n_calls) *n_calls = (int)b->calls;
     if (score_ms) *score_ms = (float)a;
     if (merge_ms) *merge_ms = (float)c;
+    return MSR_OK;
+}
+
+int msr_batch_debug_stamps(msr_batch* b, unsigned long long out[8]) {
+    if (!b || !out) {
+        set_error("msr_batch_debug_stamps: bad argument");
+        return MSR_E_INVAL;
+    }
+    memset(out, 0, 8 * sizeof(unsigned long long));
+    if (!b->d_stamps) return MSR_OK;
+    int rc = msr_batch_sync(b);
+    if (rc != MSR_OK) return rc;
+    HIP_TRY(hipMemcpy(out, b->d_stamps, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     return MSR_OK;
 }
 

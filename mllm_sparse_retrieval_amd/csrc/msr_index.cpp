@@ -347,7 +347,9 @@ int build_from_csr(const char* out_path, uint64_t n_docs, uint32_t n_terms, cons
     }
     seg_ptr.resize((uint64_t)n_tiles * stride);
 
-    // ---- fill postings, tile-parallel
+    // ---- fill postings, tile-parallel. Inside a segment the postings are sorted by ordinal and then laid out
+    // chunk-interleaved (msr_internal.h): so that one wave's uint4 load of a chunk hands lane l the postings
+    // l, l+nv, l+2nv, l+3nv of that chunk — consecutive lanes then hit consecutive accumulators (LDS banks).
     std::vector<uint32_t> postings;
     try {
         postings.assign(n_vecs * 4, 0u);
@@ -358,19 +360,42 @@ int build_from_csr(const char* out_path, uint64_t n_docs, uint32_t n_terms, cons
     next_tile = 0;
     parallel_run(threads, [&](int) {
         std::vector<std::pair<uint32_t, uint32_t>> buf;
-        std::vector<uint32_t> cursor(n_terms);
+        std::vector<uint32_t> cursor(n_terms), seg_cnt(n_terms);
         for (;;) {
             uint32_t tile = next_tile.fetch_add(1);
             if (tile >= n_tiles) break;
             const uint32_t* p = seg_ptr.data() + (uint64_t)tile * stride;
             uint64_t o0 = (uint64_t)tile * tile_docs, o1 = std::min<uint64_t>(o0 + tile_docs, n_docs);
-            // cursor is relative to the tile's first posting so it fits 32 bits
-            const uint64_t tile_base = (uint64_t)p[0] * 4;
-            for (uint32_t v = 0; v < n_terms; ++v) cursor[v] = (uint32_t)((uint64_t)p[v] * 4 - tile_base);
+            std::fill(cursor.begin(), cursor.end(), 0u);
+            // pass A: how many postings each segment holds (needed to place an entry inside its chunk)
+            std::fill(seg_cnt.begin(), seg_cnt.end(), 0u);
             for (uint64_t o = o0; o < o1; ++o) {
                 gather_doc(row_of_ord[o], buf);
-                uint32_t local = (uint32_t)(o - o0);
-                for (auto& e : buf) postings[tile_base + cursor[e.first]++] = (e.second << 16) | local;
+                for (auto& e : buf) seg_cnt[e.first]++;
+            }
+            // pass B: place. Entry i of a segment lives in chunk c = i / 256 at position j = i % 256; a chunk with
+            // m entries spans nv = ceil(m/4) vecs and entry j sits at vec (j % nv), element (j / nv).
+            for (uint64_t o = o0; o < o1; ++o) {
+                gather_doc(row_of_ord[o], buf);
+                const uint32_t local = (uint32_t)(o - o0);
+                for (auto& e : buf) {
+                    const uint32_t i = cursor[e.first]++;
+                    const uint32_t c = i / kChunkPostings, j = i % kChunkPostings;
+                    const uint32_t m = std::min<uint32_t>(kChunkPostings, seg_cnt[e.first] - c * kChunkPostings);
+                    const uint32_t nv = (m + 3) / 4;
+                    const uint64_t vec = (uint64_t)p[e.first] + (uint64_t)c * (kChunkPostings / 4) + (j % nv);
+                    postings[vec * 4 + j / nv] = (e.second << 16) | local;
+                }
+            }
+            // padding: weight 0 (adds nothing) with a lane-distinct ordinal, so that the padded lanes of one LDS
+            // atomic do not pile onto one accumulator
+            for (uint32_t v = 0; v < n_terms; ++v) {
+                const uint32_t cntv = seg_cnt[v];
+                const uint32_t m = cntv % kChunkPostings;
+                if (m == 0 || m % 4 == 0) continue;
+                const uint32_t nv = (m + 3) / 4;
+                const uint64_t vec0 = (uint64_t)p[v] + (uint64_t)(cntv / kChunkPostings) * (kChunkPostings / 4);
+                for (uint32_t j = m; j < nv * 4; ++j) postings[(vec0 + j % nv) * 4 + j / nv] = j % nv;
             }
         }
     });

@@ -20,8 +20,12 @@ namespace msr {
 //   (tie rule T1 for free), and cut into tiles of `tile_docs` consecutive ordinals. For every
 //   (tile, term) pair the postings of that term that fall into that tile form one SEGMENT:
 //
-//     posting  = u32   (weight << 16) | (ordinal - tile*tile_docs)      weight in [1, 65535]
-//     segment  = postings sorted by ordinal, zero-padded to a multiple of 4 (one 16-byte "vec")
+//     posting  = u32   (weight << 16) | (ordinal - tile*tile_docs)      weight in [1, 65535]; weight 0 = padding
+//     segment  = postings sorted by ordinal, zero-padded to a multiple of 4 (one 16-byte "vec"), stored
+//                chunk-interleaved: a chunk is 256 consecutive postings (64 vecs, one wave-wide uint4 load);
+//                inside a chunk of m postings spanning nv = ceil(m/4) vecs, posting j sits at vec j % nv,
+//                element j / nv — lane l of a wave therefore receives postings l, l+nv, l+2nv, l+3nv, and the
+//                64 lanes of one LDS atomic touch (nearly) consecutive accumulators instead of a stride of 4
 //     seg_ptr  = u32[n_tiles][n_terms+1]  first vec of each segment (absolute vec index)
 //
 //   Segments of one tile are contiguous (term-major inside the tile), so one tile's slice of the
@@ -62,6 +66,7 @@ struct IndexHeader {
 constexpr uint32_t kIndexVersion = 1;
 constexpr uint32_t kDefaultTileDocs = 32768;
 constexpr uint32_t kMaxWeight = 65535;
+constexpr uint32_t kChunkPostings = 256;  // postings per chunk (64 lanes x uint4)
 
 // thread-local error message (msr_last_error)
 void set_error(const char* fmt, ...) __attribute__((format(printf, 1, 2)));

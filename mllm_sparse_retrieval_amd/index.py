@@ -245,6 +245,11 @@ class QueryBatch:
         check(lib().msr_batch_timing_sum(self._h, C.byref(n), C.byref(a), C.byref(b)))
         return n.value, a.value, b.value
 
+    def debug_stamps(self):
+        out = np.zeros(8, dtype=np.uint64)
+        check(lib().msr_batch_debug_stamps(self._h, ptr(out)))
+        return out
+
     def algo_bytes(self, k):
         by, po = C.c_uint64(), C.c_uint64()
         check(lib().msr_batch_algo_bytes(self._h, int(k), C.byref(by), C.byref(po)))

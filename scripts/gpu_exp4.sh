@@ -1,0 +1,11 @@
+cd $GRAFT_REPO_ROOT
+export TMPDIR=/tmp
+timeout -k 10 600 python3 -m pytest tests -m gpu -x -q 2>&1 | tail -3
+B="python3 bench.py --only-c4 --no-cpu --steps 5 --warmup 1"
+P='import json,sys; d=json.load(sys.stdin)["c4_1m"]; print(d["value"], d["roofline"]["kernel_ms"])'
+for t in 32768 16384; do
+  echo "== tile $t"; $B --c4-tile-docs $t 2>/dev/null | python3 -c "$P"
+  echo "== stamps tile $t"; MSR_DEBUG_FLAGS=8 $B --c4-tile-docs $t 2>gpurun_out/e.err | python3 -c "$P"; grep "phase shares" gpurun_out/e.err
+done
+echo "== headline"; python3 bench.py --no-c4 --no-cpu --steps 10 --warmup 2 2>/dev/null | python3 -c 'import json,sys; d=json.load(sys.stdin); print(d["value"], d["roofline"]["kernel_ms"])'
+echo "== headline stamps"; MSR_DEBUG_FLAGS=8 python3 bench.py --no-c4 --no-cpu --steps 10 --warmup 2 2>gpurun_out/e.err | python3 -c 'import json,sys; d=json.load(sys.stdin); print(d["value"], d["roofline"]["kernel_ms"])'; grep "phase shares" gpurun_out/e.err

@@ -44,11 +44,18 @@ def index_file_to_dense(ix):
         for t in range(ix["n_terms"]):
             a, b = int(ix["seg_ptr"][tile, t]) * 4, int(ix["seg_ptr"][tile, t + 1]) * 4
             seg = ix["postings"][a:b]
-            real = seg[seg != 0]
-            # padding only at the end of a segment, ordinals ascending inside it
-            assert (seg[: len(real)] == real).all()
+            # undo the chunk interleave (csrc/msr_internal.h): chunk of m postings over nv vecs, posting j at
+            # vec j % nv, element j / nv  ->  reading element-major gives the postings in ordinal order
+            real = []
+            for c0 in range(0, len(seg), 256):
+                ch = seg[c0 : c0 + 256].reshape(-1, 4)
+                flat = ch.T.reshape(-1)
+                nz = flat[(flat >> 16) != 0]  # weight 0 = padding
+                assert (flat[: len(nz)] == nz).all(), "padding must trail the chunk"
+                real.append(nz)
+            real = np.concatenate(real) if real else np.zeros(0, np.uint32)
             loc = (real & 0xFFFF).astype(np.int64)
-            assert (np.diff(loc) > 0).all()
+            assert (np.diff(loc) > 0).all(), "ordinals ascend inside a segment"
             D[tile * ix["tile_docs"] + loc, t] += (real >> 16).astype(np.int64)
     return D
 
