@@ -281,30 +281,34 @@ __global__ __launch_bounds__(NT, MIN_WAVES) void score_tiles(const ScoreArgs a) 
                 m_w = seg_w[lo];
             }
             const uint32_t nchunk = min(64u, c_end - cb);
-            for (uint32_t u0 = 0; u0 < nchunk; u0 += U) {
-                uint4 v[U];
-                uint32_t w[U], n[U];
+            // Software pipeline, two register banks of U chunks: the next bank's 1-KiB loads are in flight while
+            // the current bank's LDS atomics issue. Loads are unconditional (lanes past a chunk's end, and chunk
+            // slots past nchunk, re-read the chunk's / the shard's first vec) so that the compiler can count them
+            // with s_waitcnt vmcnt(N) instead of draining to vmcnt(0); only the atomics are predicated.
+            auto load_bank = [&](uint4 (&v)[U], uint32_t u0) {
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const uint32_t idx = (u0 + u) & 63u;
+                    const uint32_t b = rdl(m_base, idx);
+                    const uint32_t n = rdl(m_n, idx);
+                    if (DBG && (a.dbg & 2u)) {  // ablation: no global loads, synthetic postings
+                        const uint32_t hsh = ((cb + idx) * 64u + lane) * 2654435761u;
+                        v[u] = make_uint4((1u << 16) | (hsh >> 17), (1u << 16) | ((hsh * 31u) >> 17),
+                                          (1u << 16) | ((hsh * 131u) >> 17), (1u << 16) | ((hsh * 1031u) >> 17));
+                    } else {
+                        v[u] = post4[b + (lane < n ? lane : 0u)];
+                    }
+                }
+            };
+            auto add_bank = [&](const uint4 (&v)[U], uint32_t u0) {
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
                     const uint32_t idx = u0 + u;
-                    const uint32_t b = rdl(m_base, idx & 63);
-                    n[u] = idx < nchunk ? rdl(m_n, idx & 63) : 0u;
-                    w[u] = rdl(m_w, idx & 63);
-                    if (lane < n[u]) {
-                        if (DBG && (a.dbg & 2u)) {  // ablation: no global loads, synthetic postings
-                            const uint32_t hsh = ((cb + idx) * 64u + lane) * 2654435761u;
-                            v[u] = make_uint4((1u << 16) | (hsh >> 17), (1u << 16) | ((hsh * 31u) >> 17),
-                                              (1u << 16) | ((hsh * 131u) >> 17), (1u << 16) | ((hsh * 1031u) >> 17));
-                        } else {
-                            v[u] = post4[b + lane];
-                        }
-                    }
-                }
-#pragma unroll
-                for (int u = 0; u < U; ++u) {
-                    // lanes past the chunk's last vec hold nothing and must not touch LDS (64 lanes adding 0 to one
-                    // accumulator would serialise); padding INSIDE a vec has weight 0 and a lane-distinct ordinal
-                    if (lane < n[u]) {
+                    const uint32_t n = idx < nchunk ? rdl(m_n, idx & 63u) : 0u;
+                    const uint32_t w = rdl(m_w, idx & 63u);
+                    // lanes past the chunk's last vec must not touch LDS (64 lanes adding to one accumulator would
+                    // serialise); padding INSIDE a vec has weight 0 and a lane-distinct ordinal
+                    if (lane < n) {
                         const uint32_t p[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
                         if (DBG && (a.dbg & 1u)) {  // ablation: no LDS atomics (keep the loads alive)
                             if ((p[0] ^ p[1] ^ p[2] ^ p[3]) == 0xDEADBEEFu) atomicAdd(&acc[0], 1u);
@@ -312,9 +316,20 @@ __global__ __launch_bounds__(NT, MIN_WAVES) void score_tiles(const ScoreArgs a) 
 #pragma unroll
                             for (int e = 0; e < 4; ++e)
                                 atomicAdd(&acc[DBG ? (p[e] & 0xFFFFu) % TILE_DOCS : (p[e] & 0xFFFFu)],
-                                          __umul24(p[e] >> 16, w[u]));
+                                          __umul24(p[e] >> 16, w));
                         }
                     }
+                }
+            };
+            uint4 va[U], vb[U];
+            load_bank(va, 0);
+            for (uint32_t u0 = 0; u0 < nchunk; u0 += 2 * U) {
+                const bool more = u0 + U < nchunk;  // wave-uniform
+                if (more) load_bank(vb, u0 + U);
+                add_bank(va, u0);
+                if (more) {
+                    if (u0 + 2 * U < nchunk) load_bank(va, u0 + 2 * U);
+                    add_bank(vb, u0 + U);
                 }
             }
         }
@@ -634,7 +649,8 @@ int device_attach(msr_index* ix, int device) {
         d->vec_base = sp[0];
         d->shard_vecs = (uint64_t)sp[(uint64_t)(nt - 1) * stride + h->n_terms] - d->vec_base;
         const size_t seg_bytes = (size_t)nt * stride * 4;
-        const size_t post_bytes = std::max<size_t>((size_t)d->shard_vecs * 16, 16);
+        // the kernel's unconditional loads may read the first 64 vecs of the shard even when it holds fewer
+        const size_t post_bytes = std::max<size_t>((size_t)d->shard_vecs * 16, 64 * 16);
         if (hipMalloc(&d->d_seg_ptr, seg_bytes) != hipSuccess || hipMalloc(&d->d_postings, post_bytes) != hipSuccess) {
             set_error("hipMalloc of %zu + %zu bytes for the index shard failed", seg_bytes, post_bytes);
             return fail(MSR_E_NOMEM);
