@@ -1,0 +1,167 @@
+"""encode -> index -> search, with the reference's flag names (src/arguments.py:57-68, scripts/*.sh).
+
+    python -m mllm_sparse_retrieval_amd encode --synthetic flickr --sparse_output_dir out/        (no MLLM here)
+    python -m mllm_sparse_retrieval_amd index  --input out/ [--index out/index] --threads 16       (sparse_index.sh)
+    python -m mllm_sparse_retrieval_amd search --sparse_index out/ --depth 10 --query_type text \\
+           --dataset_name flickr --queries out/query.tsv --qrels out/qrels.csv --save_dir runs/   (search_sparse.sh)
+
+`encode` writes exactly the files src/encode.py:412-426 writes (corpus_{shard}.jsonl, query.tsv); `index` accepts and
+ignores pyserini's --collection/--generator/--impact/--pretokenized; `search` prints recall in the reference's format
+(src/metrices.py:103-137) and writes TREC runs (src/hybrid.py:20-29) under --save_dir.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+from types import SimpleNamespace
+
+
+def _cmd_encode(a):
+    import numpy as np
+
+    from . import workloads
+
+    if a.synthetic is None:
+        sys.exit("encode: only --synthetic {flickr,coco} is available (the MLLM encoder is out of scope here)")
+    if a.synthetic == "flickr":
+        wl = workloads.flickr30k_t2i(n_images=a.n_images or 1000, seed=a.seed, threads=a.threads)
+        name = "flickr"
+    else:
+        wl = workloads.flickr30k_t2i(n_images=a.n_images or 5000, n_terms=30000, seed=a.seed, threads=a.threads)
+        name = "coco"
+    out = a.sparse_output_dir
+    os.makedirs(out, exist_ok=True)
+    dp, dt, dw = wl.docs
+    with open(os.path.join(out, f"corpus_{a.dataset_shard_index}.jsonl"), "w") as f:
+        for i in range(len(dp) - 1):
+            vec = {f"t{int(t)}": int(w) for t, w in zip(dt[dp[i]:dp[i + 1]], dw[dp[i]:dp[i + 1]])}
+            f.write(json.dumps(dict(id=str(i), content="", vector=vec)) + "\n")
+    qp, qt, qw = wl.queries
+    with open(os.path.join(out, "query.tsv"), "w") as f:
+        for i in range(len(qp) - 1):
+            toks = " ".join(" ".join([f"t{int(t)}"] * int(w)) for t, w in zip(qt[qp[i]:qp[i + 1]], qw[qp[i]:qp[i + 1]]))
+            if toks.strip():
+                f.write(f"{i}\t{toks}\n")
+    with open(os.path.join(out, "qrels.csv"), "w") as f:  # flickr csv schema (src/dataset.py:86-102)
+        f.write("imgid,filename,caption,sentid\n")
+        for i in range(len(qp) - 1):
+            f.write(f"{i // 5},{i // 5}.jpg,,{i}\n")
+    print(f"encode: {len(dp) - 1} docs, {len(qp) - 1} queries ({name}-shape, synthetic) -> {out}")
+
+
+def _cmd_index(a):
+    from .index import build_index_from_jsonl
+
+    out = os.path.join(a.index, "msr.idx") if a.index else None
+    if a.index:
+        os.makedirs(a.index, exist_ok=True)
+    t0 = time.time()
+    path = build_index_from_jsonl(a.input, out, threads=a.threads, tile_docs=a.tile_docs)
+    print(f"index: {path} ({os.path.getsize(path) / 1e6:.1f} MB) in {time.time() - t0:.2f}s")
+
+
+def read_queries(path):
+    """query.tsv (`id\\ttok tok tok`, src/encode.py:418-424) or query jsonl ({"id","vector"}) -> (ids, strings)."""
+    ids, texts = [], []
+    with open(path, encoding="utf-8") as f:
+        if path.endswith((".jsonl", ".json")):
+            for line in f:
+                if line.strip():
+                    o = json.loads(line)
+                    ids.append(str(o["id"]))
+                    texts.append(" ".join(" ".join([t] * int(v)) for t, v in o["vector"].items() if int(v) > 0))
+        else:
+            for line in f:
+                line = line.rstrip("\n")
+                if line:
+                    qid, _, text = line.partition("\t")
+                    ids.append(qid)
+                    texts.append(text)
+    return ids, texts
+
+
+def _cmd_search(a):
+    from .fusion import write_trec_run
+    from .qrels import CrossModalQrels
+    from .recall import RecallMetrics
+    from .run import get_run_dict, sparse_search
+    from .searcher import JWhiteSpaceAnalyzer, LuceneImpactSearcher
+
+    if a.passage_reps is not None:
+        sys.exit("search: --passage_reps (dense / hybrid) is not available in this build yet; sparse only")
+    searcher = LuceneImpactSearcher(os.path.join(a.sparse_index, "index") if os.path.isdir(
+        os.path.join(a.sparse_index, "index")) else a.sparse_index, None, device=a.device)
+    searcher.set_analyzer(JWhiteSpaceAnalyzer())
+    qids, texts = read_queries(a.queries or os.path.join(a.sparse_index, "query.tsv"))
+    bs = a.batch_size if a.batch_size > 0 else len(qids)
+    args = SimpleNamespace(depth=a.depth, threads=a.threads, query_type=a.query_type)
+    sparse_run = {}
+    t0 = time.time()
+    for i in range(0, len(qids), bs):
+        scores, rankings = sparse_search(searcher, texts[i:i + bs], qids[i:i + bs], args)
+        sparse_run.update(get_run_dict(qids[i:i + bs], scores, rankings, a.remove_query))
+    dt = time.time() - t0
+    if not a.quiet:
+        print(f"search: {len(qids)} queries in {dt:.3f}s ({len(qids) / max(dt, 1e-9):.0f} q/s end-to-end incl. host)")
+    if a.save_dir:
+        os.makedirs(a.save_dir, exist_ok=True)
+        write_trec_run(sparse_run, os.path.join(a.save_dir, "sparse.trec"), name="sparse")
+    if a.qrels:
+        ds = CrossModalQrels(a.qrels, a.dataset_name)
+        m = RecallMetrics(ds, {}, sparse_run, {}, [], qids, args)
+        m.sort_and_count()
+        m.all_gather_object()
+        m.print_recall()
+
+
+def main(argv=None):
+    ap = argparse.ArgumentParser(prog="mllm_sparse_retrieval_amd")
+    sub = ap.add_subparsers(dest="cmd", required=True)
+
+    e = sub.add_parser("encode")
+    e.add_argument("--synthetic", choices=["flickr", "coco"])
+    e.add_argument("--sparse_output_dir", default="./sparse_output/")
+    e.add_argument("--dataset_shard_index", type=int, default=0)
+    e.add_argument("--n_images", type=int, default=0)
+    e.add_argument("--seed", type=int, default=1)
+    e.add_argument("--threads", type=int, default=16)
+    e.set_defaults(fn=_cmd_encode)
+
+    i = sub.add_parser("index")
+    i.add_argument("--input", required=True)
+    i.add_argument("--index", default=None)
+    i.add_argument("--threads", type=int, default=16)
+    i.add_argument("--tile_docs", type=int, default=0)
+    for flag in ("--collection", "--generator"):  # pyserini flags of scripts/sparse_index.sh, accepted and ignored
+        i.add_argument(flag, default=None)
+    i.add_argument("--impact", action="store_true")
+    i.add_argument("--pretokenized", action="store_true")
+    i.set_defaults(fn=_cmd_index)
+
+    s = sub.add_parser("search")
+    s.add_argument("--sparse_index", required=True)
+    s.add_argument("--passage_reps", default=None)
+    s.add_argument("--depth", type=int, default=1000)
+    s.add_argument("--threads", type=int, default=1)
+    s.add_argument("--batch_size", type=int, default=128)
+    s.add_argument("--alpha", type=float, default=0.5)
+    s.add_argument("--remove_query", action="store_true")
+    s.add_argument("--query_type", default="text")
+    s.add_argument("--dataset_name", default="flickr")
+    s.add_argument("--save_dir", default=None)
+    s.add_argument("--quiet", action="store_true")
+    s.add_argument("--use_gpu", action="store_true")
+    s.add_argument("--queries", default=None)
+    s.add_argument("--qrels", default=None)
+    s.add_argument("--device", type=int, default=0)
+    s.set_defaults(fn=_cmd_search)
+
+    a = ap.parse_args(argv)
+    a.fn(a)
+
+
+if __name__ == "__main__":
+    main()

