@@ -64,13 +64,18 @@ typedef struct msr_info {
     uint32_t shard_tile0;   /* first tile resident on this handle */
     uint32_t shard_ntiles;  /* tiles resident on this handle */
     int32_t device;         /* HIP device ordinal, or -1 */
-    int32_t reserved;
+    uint32_t n_dense;       /* terms stored in the dense head */
 } msr_info;
 
 /* ---- index build: replaces scripts/sparse_index.sh:12-18 (pyserini.index.lucene --impact --pretokenized) ----
  * Reads every *.jsonl / *.json file of `jsonl_dir` (lines {"id":…,"content":…,"vector":{tok:int}} as written by
  * src/encode.py:351-359,426) and writes one index file. tile_docs = 0 picks the default (32768). */
 int msr_index_build(const char* jsonl_dir, const char* out_path, int threads, uint32_t tile_docs);
+
+/* Process-wide build options (set before building; not thread-safe):
+ *   "dense_min_density" (default 0.4): a term with df >= density * n_docs is stored in the doc-major dense head
+ *   "dense_max_terms"   (default 16, at most 32; 0 disables the dense head) */
+int msr_set_build_option(const char* key, double value);
 
 /* Same index from a doc-major CSR already in memory (used by the synthetic encode step and the benchmark).
  * doc_ids / term_strs may be NULL: docs are then named by their decimal row number and terms by their decimal id. */

@@ -37,13 +37,14 @@ class MsrInfo(C.Structure):
     _fields_ = [
         ("n_docs", C.c_uint64), ("n_postings", C.c_uint64), ("n_vecs", C.c_uint64),
         ("n_terms", C.c_uint32), ("tile_docs", C.c_uint32), ("n_tiles", C.c_uint32), ("max_weight", C.c_uint32),
-        ("shard_tile0", C.c_uint32), ("shard_ntiles", C.c_uint32), ("device", C.c_int32), ("reserved", C.c_int32),
+        ("shard_tile0", C.c_uint32), ("shard_ntiles", C.c_uint32), ("device", C.c_int32), ("n_dense", C.c_uint32),
     ]
 
 
 # every symbol include/msr.h declares: (name, restype, argtypes)
 _VP, _CP, _I, _U32, _U64 = C.c_void_p, C.c_char_p, C.c_int, C.c_uint32, C.c_uint64
 SYMBOLS = [
+    ("msr_set_build_option", _I, [_CP, C.c_double]),
     ("msr_index_build", _I, [_CP, _CP, _I, _U32]),
     ("msr_index_build_csr", _I, [_CP, _U64, _U32, _VP, _VP, _VP, _VP, _VP, _I, _U32]),
     ("msr_index_open", _I, [_CP, _I, C.POINTER(_VP)]),

@@ -51,6 +51,8 @@ struct DeviceIndex {
     hipStream_t stream = nullptr;
     uint32_t* d_seg_ptr = nullptr;   // [shard_ntiles][n_terms+1] absolute vec index
     uint32_t* d_postings = nullptr;  // the shard's vecs; vec v of the index lives at d_postings + (v - vec_base)*4
+    uint32_t* d_dense = nullptr;     // [shard_ntiles][n_pairs][tile_docs] dense head of the shard's tiles
+    uint32_t n_pairs = 0;
     uint32_t vec_base = 0;
     uint64_t shard_vecs = 0;
     std::vector<uint32_t> df_shard;  // postings of each term inside this shard (for algorithmic bytes)
@@ -125,6 +127,9 @@ struct ScoreArgs {
     const uint32_t* q_ptr;     // [nq+1]
     const uint32_t* q_term;
     const uint32_t* q_w;
+    const uint32_t* dense;     // [ntiles][n_pairs][TILE_DOCS] dense head (weights of term 2p+1 << 16 | term 2p)
+    const uint32_t* q_dense;   // [nq][n_pairs] packed query weights of the dense-head terms (0 = absent)
+    uint32_t n_pairs;
     uint64_t* part;            // [ntiles][nq][k] keys
     uint64_t n_docs;           // whole index
     uint32_t vec_base;
@@ -210,8 +215,66 @@ __global__ __launch_bounds__(NT, MIN_WAVES) void score_tiles(const ScoreArgs a) 
         pre_s1 = seg_row[t + 1];
     }
 
-    // ---- zero the accumulators that can be touched
-    for (int r = 0; r < rounds; ++r) a4[r * NT + tid] = make_uint4(0, 0, 0, 0);
+    // ---- initialise the accumulators: zero, or — when the query holds dense-head terms — their whole contribution.
+    // Thread `tid` owns vecs r*NT + tid (4 consecutive docs each); the dense head is doc-major, one dword per doc and
+    // term pair, so the owner scores two postings per v_dot2_u32_u16 and stores the sums with a plain ds_write_b128:
+    // no atomics, and no separate zeroing pass. Term pairs the query does not hold are skipped (wave-uniform bit
+    // mask); the rows of the next pair are in flight while the current pair is accumulated (two register banks).
+    {
+        typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+        constexpr int RG = 4;  // rounds per register group
+        const uint32_t qv = lane < a.n_pairs ? a.q_dense[(uint64_t)q * a.n_pairs + lane] : 0u;
+        const unsigned long long pmask = (DBG && (a.dbg & 16u)) ? 0ull : __ballot(qv != 0);
+        const uint4* dblk = reinterpret_cast<const uint4*>(a.dense) + (uint64_t)tile_l * a.n_pairs * (TILE_DOCS / 4);
+        for (int r0 = 0; r0 < rounds; r0 += RG) {
+            uint4 sacc[RG];
+#pragma unroll
+            for (int i = 0; i < RG; ++i) sacc[i] = make_uint4(0, 0, 0, 0);
+            if (pmask) {
+                auto load_rows = [&](uint4 (&x)[RG], uint32_t p) {
+#pragma unroll
+                    for (int i = 0; i < RG; ++i)  // rows past `rounds` re-read the last real round (result unused)
+                        x[i] = dblk[(uint64_t)p * (TILE_DOCS / 4) + (uint32_t)min(r0 + i, rounds - 1) * NT + tid];
+                };
+                auto add_rows = [&](const uint4 (&x)[RG], uint32_t qp) {
+                    const us2 qq = __builtin_bit_cast(us2, qp);
+#pragma unroll
+                    for (int i = 0; i < RG; ++i) {
+                        sacc[i].x = __builtin_amdgcn_udot2(__builtin_bit_cast(us2, x[i].x), qq, sacc[i].x, false);
+                        sacc[i].y = __builtin_amdgcn_udot2(__builtin_bit_cast(us2, x[i].y), qq, sacc[i].y, false);
+                        sacc[i].z = __builtin_amdgcn_udot2(__builtin_bit_cast(us2, x[i].z), qq, sacc[i].z, false);
+                        sacc[i].w = __builtin_amdgcn_udot2(__builtin_bit_cast(us2, x[i].w), qq, sacc[i].w, false);
+                    }
+                };
+                unsigned long long m = pmask;
+                uint4 xa[RG], xb[RG];
+                uint32_t pa = (uint32_t)__builtin_ctzll(m), pb = 0;
+                m &= m - 1;
+                load_rows(xa, pa);
+                for (;;) {
+                    const bool more_b = m != 0;
+                    if (more_b) {
+                        pb = (uint32_t)__builtin_ctzll(m);
+                        m &= m - 1;
+                        load_rows(xb, pb);
+                    }
+                    add_rows(xa, rdl(qv, pa));
+                    if (!more_b) break;
+                    const bool more_a = m != 0;
+                    if (more_a) {
+                        pa = (uint32_t)__builtin_ctzll(m);
+                        m &= m - 1;
+                        load_rows(xa, pa);
+                    }
+                    add_rows(xb, rdl(qv, pb));
+                    if (!more_a) break;
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < RG; ++i)
+                if (r0 + i < rounds) a4[(r0 + i) * NT + tid] = sacc[i];
+        }
+    }
     if (tid < 64) ss.cnt[tid] = 0;
     if (tid == 0) {
         ss.n_cand = 0;
@@ -655,6 +718,17 @@ int device_attach(msr_index* ix, int device) {
             set_error("hipMalloc of %zu + %zu bytes for the index shard failed", seg_bytes, post_bytes);
             return fail(MSR_E_NOMEM);
         }
+        d->n_pairs = h->n_dense / 2;
+        const size_t dense_bytes = std::max<size_t>((size_t)nt * d->n_pairs * h->tile_docs * 4, 16);
+        if (hipMalloc(&d->d_dense, dense_bytes) != hipSuccess) {
+            set_error("hipMalloc of %zu bytes for the dense head failed", dense_bytes);
+            return fail(MSR_E_NOMEM);
+        }
+        if (d->n_pairs && hipMemcpy(d->d_dense, ix->host.dense + (uint64_t)t0 * d->n_pairs * h->tile_docs,
+                                    (size_t)nt * d->n_pairs * h->tile_docs * 4, hipMemcpyHostToDevice) != hipSuccess) {
+            set_error("upload of the dense head failed");
+            return fail(MSR_E_HIP);
+        }
         if (hipMemcpy(d->d_seg_ptr, sp, seg_bytes, hipMemcpyHostToDevice) != hipSuccess ||
             (d->shard_vecs && hipMemcpy(d->d_postings, ix->host.postings + (uint64_t)d->vec_base * 4,
                                         (size_t)d->shard_vecs * 16, hipMemcpyHostToDevice) != hipSuccess)) {
@@ -672,6 +746,7 @@ void device_detach(msr_index* ix) {
     if (d->comm) ncclCommDestroy(d->comm);
     if (d->d_seg_ptr) (void)hipFree(d->d_seg_ptr);
     if (d->d_postings) (void)hipFree(d->d_postings);
+    if (d->d_dense) (void)hipFree(d->d_dense);
     if (d->stream) (void)hipStreamDestroy(d->stream);
     delete d;
     ix->dev = nullptr;
@@ -699,6 +774,17 @@ static void compute_df_shard(msr_index* ix) {
                 for (uint32_t i = 0; i < tail * 4; ++i) zeros += (last[i] >> 16) == 0;
                 d->df_shard[v] += len * 4 - zeros;
             }
+            const uint32_t np = h->n_dense / 2;
+            const uint32_t* dt = ix->host.dense + (uint64_t)t * np * h->tile_docs;
+            for (uint32_t s2 = 0; s2 < h->n_dense; ++s2) {
+                const uint32_t term = ix->host.dense_terms[s2];
+                if (term == 0xFFFFFFFFu) continue;
+                const uint32_t* row = dt + (uint64_t)(s2 >> 1) * h->tile_docs;
+                const uint32_t sh = 16 * (s2 & 1);
+                uint32_t c = 0;
+                for (uint32_t i = 0; i < h->tile_docs; ++i) c += ((row[i] >> sh) & 0xFFFFu) != 0;
+                d->df_shard[term] += c;
+            }
         }
     }
     d->df_shard_ready = true;
@@ -719,6 +805,7 @@ struct msr_batch {
     uint32_t* d_qptr = nullptr;
     uint32_t* d_qterm = nullptr;
     uint32_t* d_qw = nullptr;
+    uint32_t* d_qdense = nullptr; // [nq][n_pairs]
     uint64_t* d_part = nullptr;   // [ntiles][nq][kmax]
     uint64_t* d_keys = nullptr;   // [nq][kmax] local top-k keys
     uint64_t* d_gather = nullptr; // [n_ranks][nq][kmax] (sharded search)
@@ -736,7 +823,7 @@ struct msr_batch {
 static void batch_free(msr_batch* b) {
     if (!b) return;
     if (b->ix && b->ix->dev) (void)hipSetDevice(b->ix->dev->device);
-    void* ptrs[] = {b->d_qptr, b->d_qterm, b->d_qw, b->d_part, b->d_keys, b->d_gather, b->d_ord, b->d_su32, b->d_sf32, b->d_n,
+    void* ptrs[] = {b->d_qptr, b->d_qterm, b->d_qw, b->d_qdense, b->d_part, b->d_keys, b->d_gather, b->d_ord, b->d_su32, b->d_sf32, b->d_n,
                     b->d_stamps};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
@@ -781,6 +868,10 @@ int msr_batch_create(msr_index* ix, const int64_t* q_ptr, const int32_t* q_term,
     }
     qterm.reserve((size_t)total_in);
     qw.reserve((size_t)total_in);
+    const uint32_t n_pairs = h->n_dense / 2;
+    std::vector<uint32_t> qdense((size_t)nq * n_pairs, 0u);  // packed 16-bit query weights of the dense-head terms
+    std::vector<uint32_t> dsum(h->n_dense);
+    uint64_t n_kept = 0;
     uint64_t sum_df = 0;
     for (int i = 0; i < nq; ++i) {
         if (q_ptr[i + 1] < q_ptr[i] || q_ptr[i + 1] > total_in) {
@@ -788,6 +879,7 @@ int msr_batch_create(msr_index* ix, const int64_t* q_ptr, const int32_t* q_term,
             return MSR_E_INVAL;
         }
         uint64_t bound = 0;
+        std::fill(dsum.begin(), dsum.end(), 0u);
         for (int64_t e = q_ptr[i]; e < q_ptr[i + 1]; ++e) {
             const int32_t t = q_term[e];
             const int32_t w = q_w[e];
@@ -803,10 +895,22 @@ int msr_batch_create(msr_index* ix, const int64_t* q_ptr, const int32_t* q_term,
             if ((flags & MSR_F_DROP_DF_EQ_N) && ix->host.df[t] == h->n_docs) continue;
             if (ix->host.df[t] == 0) continue;
             bound += (uint64_t)w * ix->host.maxw[t];
-            qterm.push_back((uint32_t)t);
-            qw.push_back((uint32_t)w);
             sum_df += d->df_shard[t];
+            ++n_kept;
+            const int ds = ix->host.dense_slot[t];
+            if (ds >= 0) {  // dense-head term: repeated entries add up; v_dot2_u32_u16 takes 16-bit weights
+                if ((uint64_t)dsum[ds] + (uint64_t)w > 0xFFFFull) {
+                    set_error("query %d: weight of dense-head term %d exceeds the supported maximum 65535", i, t);
+                    return MSR_E_RANGE;
+                }
+                dsum[ds] += (uint32_t)w;
+            } else {
+                qterm.push_back((uint32_t)t);
+                qw.push_back((uint32_t)w);
+            }
         }
+        for (uint32_t s2 = 0; s2 < h->n_dense; ++s2)
+            qdense[(size_t)i * n_pairs + (s2 >> 1)] |= dsum[s2] << (16 * (s2 & 1));
         if (bound > 0xFFFFFFFFull) {
             set_error("query %d: worst-case score %llu exceeds the exact u32 range", i, (unsigned long long)bound);
             return MSR_E_OVERFLOW;
@@ -826,7 +930,7 @@ int msr_batch_create(msr_index* ix, const int64_t* q_ptr, const int32_t* q_term,
     b->ix = ix;
     b->nq = nq;
     b->kmax = kmax;
-    b->nnz = qterm.size();
+    b->nnz = n_kept;
     b->sum_df = sum_df;
     auto fail = [&](int rc) {
         batch_free(b);
@@ -841,6 +945,7 @@ int msr_batch_create(msr_index* ix, const int64_t* q_ptr, const int32_t* q_term,
     bool ok = hipMalloc(&b->d_qptr, ((size_t)nq + 1) * 4) == hipSuccess &&
               hipMalloc(&b->d_qterm, std::max<size_t>(qterm.size(), 1) * 4) == hipSuccess &&
               hipMalloc(&b->d_qw, std::max<size_t>(qw.size(), 1) * 4) == hipSuccess &&
+              hipMalloc(&b->d_qdense, std::max<size_t>(qdense.size(), 1) * 4) == hipSuccess &&
               hipMalloc(&b->d_part, ntiles * nqk * 8) == hipSuccess && hipMalloc(&b->d_keys, nqk * 8) == hipSuccess &&
               hipMalloc(&b->d_ord, nqk * 4) == hipSuccess && hipMalloc(&b->d_su32, nqk * 4) == hipSuccess &&
               hipMalloc(&b->d_sf32, nqk * 4) == hipSuccess &&
@@ -849,7 +954,8 @@ int msr_batch_create(msr_index* ix, const int64_t* q_ptr, const int32_t* q_term,
         set_error("hipMalloc for the query batch failed (%d queries, kmax %d, %zu tiles)", nq, kmax, ntiles);
         return fail(MSR_E_NOMEM);
     }
-    ok = hipMemcpy(b->d_qptr, qptr.data(), ((size_t)nq + 1) * 4, hipMemcpyHostToDevice) == hipSuccess &&
+    ok = (qdense.empty() || hipMemcpy(b->d_qdense, qdense.data(), qdense.size() * 4, hipMemcpyHostToDevice) == hipSuccess) &&
+         hipMemcpy(b->d_qptr, qptr.data(), ((size_t)nq + 1) * 4, hipMemcpyHostToDevice) == hipSuccess &&
          (qterm.empty() || (hipMemcpy(b->d_qterm, qterm.data(), qterm.size() * 4, hipMemcpyHostToDevice) == hipSuccess &&
                             hipMemcpy(b->d_qw, qw.data(), qw.size() * 4, hipMemcpyHostToDevice) == hipSuccess));
     if (!ok) {
@@ -883,6 +989,9 @@ static int batch_search_local(msr_batch* b, int k, bool final_arrays) {
     sa.q_ptr = b->d_qptr;
     sa.q_term = b->d_qterm;
     sa.q_w = b->d_qw;
+    sa.dense = d->d_dense;
+    sa.q_dense = b->d_qdense;
+    sa.n_pairs = d->n_pairs;
     sa.part = b->d_part;
     sa.n_docs = h->n_docs;
     sa.vec_base = d->vec_base;

@@ -95,10 +95,16 @@ int HostIndex::open(const char* path) {
         close();
         return MSR_E_FORMAT;
     }
+    if (h->n_dense > kMaxDense || h->n_dense % 2 != 0) {
+        set_error("index '%s': bad dense head size %u", path, h->n_dense);
+        close();
+        return MSR_E_FORMAT;
+    }
     const uint64_t want[SEC_COUNT] = {
         (uint64_t)(h->n_terms + 1ull) * 8, h->size[SEC_TERM_STR], (uint64_t)h->n_terms * 4, (uint64_t)h->n_terms * 4,
         (uint64_t)h->n_terms * 4,          (h->n_docs + 1) * 8,   h->size[SEC_DOC_STR],     (uint64_t)h->n_tiles * (h->n_terms + 1ull) * 4,
-        h->n_vecs * 16};
+        h->n_vecs * 16,                    (uint64_t)h->n_dense * 4,
+        (uint64_t)h->n_tiles * (h->n_dense / 2) * h->tile_docs * 4};
     for (int s = 0; s < SEC_COUNT; ++s) {
         if (h->size[s] != want[s] || h->off[s] % 16 != 0 || h->off[s] + h->size[s] > bytes) {
             set_error("index '%s': section %d has inconsistent offset/size", path, s);
@@ -121,6 +127,18 @@ int HostIndex::open(const char* path) {
     doc_str = (const char*)(base + h->off[SEC_DOC_STR]);
     seg_ptr = (const uint32_t*)(base + h->off[SEC_SEG_PTR]);
     postings = (const uint32_t*)(base + h->off[SEC_POSTINGS]);
+    dense_terms = (const uint32_t*)(base + h->off[SEC_DENSE_TERMS]);
+    dense = (const uint32_t*)(base + h->off[SEC_DENSE]);
+    dense_slot.assign(h->n_terms, (int8_t)-1);
+    for (uint32_t s = 0; s < h->n_dense; ++s) {
+        if (dense_terms[s] == 0xFFFFFFFFu) continue;  // padding slot of an odd-sized head
+        if (dense_terms[s] >= h->n_terms) {
+            set_error("index '%s': dense slot %u names term %u", path, s, dense_terms[s]);
+            close();
+            return MSR_E_FORMAT;
+        }
+        dense_slot[dense_terms[s]] = (int8_t)s;
+    }
     return MSR_OK;
 }
 
@@ -149,6 +167,11 @@ int32_t HostIndex::lookup(const char* tok) const {
 }
 
 // ----------------------------------------------------------------------------------------------- builder
+BuildOptions& build_options() {
+    static BuildOptions o;
+    return o;
+}
+
 namespace {
 
 struct FileWriter {
@@ -330,6 +353,30 @@ int build_from_csr(const char* out_path, uint64_t n_docs, uint32_t n_terms, cons
     df_local.clear();
     mw_local.clear();
 
+    // ---- dense head: the (at most dense_max_terms) terms with df >= dense_min_density * n_docs, by df descending
+    const BuildOptions& bo = build_options();
+    std::vector<uint32_t> dense_terms;
+    std::vector<int8_t> dense_slot(n_terms, (int8_t)-1);
+    if (bo.dense_max_terms > 0 && n_docs > 0) {
+        std::vector<uint32_t> cand;
+        const double thr = bo.dense_min_density * (double)n_docs;
+        for (uint32_t v = 0; v < n_terms; ++v)
+            if ((double)df[v] >= thr && df[v] > 0) cand.push_back(v);
+        std::sort(cand.begin(), cand.end(), [&](uint32_t a, uint32_t b) { return df[a] > df[b] || (df[a] == df[b] && a < b); });
+        if (cand.size() > std::min<uint32_t>(bo.dense_max_terms, kMaxDense)) cand.resize(std::min<uint32_t>(bo.dense_max_terms, kMaxDense));
+        dense_terms = cand;
+        if (dense_terms.size() % 2) dense_terms.push_back(0xFFFFFFFFu);  // padding slot: weights stay 0
+        for (size_t s2 = 0; s2 < dense_terms.size(); ++s2)
+            if (dense_terms[s2] != 0xFFFFFFFFu) dense_slot[dense_terms[s2]] = (int8_t)s2;
+        // dense terms have no inverted lists
+        for (uint32_t tile = 0; tile < n_tiles; ++tile) {
+            uint32_t* c = seg_ptr.data() + (uint64_t)tile * stride;
+            for (uint32_t t2 : cand) c[t2] = 0;
+        }
+    }
+    const uint32_t n_dense = (uint32_t)dense_terms.size();
+    const uint32_t n_pairs = n_dense / 2;
+
     // ---- counts -> vec offsets (each segment padded to a multiple of 4 postings)
     uint64_t n_vecs = 0;
     for (uint32_t tile = 0; tile < n_tiles; ++tile) {
@@ -357,6 +404,13 @@ int build_from_csr(const char* out_path, uint64_t n_docs, uint32_t n_terms, cons
         set_error("out of host memory for %llu posting vectors", (unsigned long long)n_vecs);
         return MSR_E_NOMEM;
     }
+    std::vector<uint32_t> dense;
+    try {
+        dense.assign((uint64_t)n_tiles * n_pairs * tile_docs, 0u);
+    } catch (const std::bad_alloc&) {
+        set_error("out of host memory for the dense head");
+        return MSR_E_NOMEM;
+    }
     next_tile = 0;
     parallel_run(threads, [&](int) {
         std::vector<std::pair<uint32_t, uint32_t>> buf;
@@ -371,14 +425,21 @@ int build_from_csr(const char* out_path, uint64_t n_docs, uint32_t n_terms, cons
             std::fill(seg_cnt.begin(), seg_cnt.end(), 0u);
             for (uint64_t o = o0; o < o1; ++o) {
                 gather_doc(row_of_ord[o], buf);
-                for (auto& e : buf) seg_cnt[e.first]++;
+                for (auto& e : buf)
+                    if (dense_slot[e.first] < 0) seg_cnt[e.first]++;
             }
+            uint32_t* dtile = dense.data() + (uint64_t)tile * n_pairs * tile_docs;
             // pass B: place. Entry i of a segment lives in chunk c = i / 256 at position j = i % 256; a chunk with
             // m entries spans nv = ceil(m/4) vecs and entry j sits at vec (j % nv), element (j / nv).
             for (uint64_t o = o0; o < o1; ++o) {
                 gather_doc(row_of_ord[o], buf);
                 const uint32_t local = (uint32_t)(o - o0);
                 for (auto& e : buf) {
+                    const int ds = dense_slot[e.first];
+                    if (ds >= 0) {
+                        dtile[(uint64_t)(ds >> 1) * tile_docs + local] |= e.second << (16 * (ds & 1));
+                        continue;
+                    }
                     const uint32_t i = cursor[e.first]++;
                     const uint32_t c = i / kChunkPostings, j = i % kChunkPostings;
                     const uint32_t m = std::min<uint32_t>(kChunkPostings, seg_cnt[e.first] - c * kChunkPostings);
@@ -445,6 +506,7 @@ int build_from_csr(const char* out_path, uint64_t n_docs, uint32_t n_terms, cons
     h.n_terms = n_terms;
     h.n_tiles = n_tiles;
     h.max_weight = gmaxw;
+    h.n_dense = n_dense;
     FileWriter w;
     if (!w.open(out_path)) {
         set_error("cannot create index file '%s': %s", out_path, strerror(errno));
@@ -473,6 +535,8 @@ int build_from_csr(const char* out_path, uint64_t n_docs, uint32_t n_terms, cons
     w.pad16();
     sec(SEC_SEG_PTR, seg_ptr.data(), seg_ptr.size() * 4);
     sec(SEC_POSTINGS, postings.data(), postings.size() * 4);
+    sec(SEC_DENSE_TERMS, dense_terms.data(), dense_terms.size() * 4);
+    sec(SEC_DENSE, dense.data(), dense.size() * 4);
     h.file_size = w.pos;
     if (!w.ok || fseek(w.f, 0, SEEK_SET) != 0) {
         w.close();
@@ -1036,6 +1100,23 @@ extern "C" {
 const char* msr_last_error(void) { return msr::last_error(); }
 const char* msr_version(void) { return "mllm_sparse_retrieval_amd 0.1 (gfx950)"; }
 
+int msr_set_build_option(const char* key, double value) {
+    if (!key) {
+        set_error("msr_set_build_option: null key");
+        return MSR_E_INVAL;
+    }
+    BuildOptions& o = build_options();
+    if (strcmp(key, "dense_min_density") == 0 && value >= 0) {
+        o.dense_min_density = value;
+    } else if (strcmp(key, "dense_max_terms") == 0 && value >= 0 && value <= kMaxDense) {
+        o.dense_max_terms = (uint32_t)value;
+    } else {
+        set_error("unknown build option '%s' or value %g out of range", key, value);
+        return MSR_E_INVAL;
+    }
+    return MSR_OK;
+}
+
 int msr_index_build(const char* jsonl_dir, const char* out_path, int threads, uint32_t tile_docs) {
     if (!jsonl_dir || !out_path) {
         set_error("msr_index_build: null path");
@@ -1134,6 +1215,7 @@ int msr_index_info(const msr_index* ix, msr_info* info) {
     info->shard_tile0 = ix->shard_tile0;
     info->shard_ntiles = ix->shard_ntiles;
     info->device = ix->dev ? ix->device : -1;
+    info->n_dense = h->n_dense;
     return MSR_OK;
 }
 

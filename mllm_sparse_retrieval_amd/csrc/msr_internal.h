@@ -31,6 +31,16 @@ namespace msr {
 //   Segments of one tile are contiguous (term-major inside the tile), so one tile's slice of the
 //   index is a contiguous byte range: that is what a doc-range shard uploads, and what the
 //   workgroups scoring that tile keep hot in their XCD's L2.
+//
+//   DENSE HEAD. Learned-sparse vocabularies have a head of terms that occur in a large share of the docs
+//   (Zipf(0.8): the top 16 terms carry 2/3 of the postings a query touches). For such terms an inverted
+//   list is the wrong shape: every posting costs an LDS atomic. The `n_dense` (even, <= 32) terms with
+//   df >= dense_min_density * n_docs are therefore stored doc-major per tile instead,
+//
+//     dense    = u32[n_tiles][n_dense/2][tile_docs]   (weight of term 2p+1) << 16 | (weight of term 2p), 0 = absent
+//
+//   have EMPTY segments, and are scored by the owning thread of each accumulator with v_dot2_u32_u16
+//   (two postings per VALU op, no atomics), which also replaces the zeroing pass of the accumulators.
 // ---------------------------------------------------------------------------------------------
 
 enum Section : int {
@@ -43,6 +53,8 @@ enum Section : int {
     SEC_DOC_STR,        // bytes
     SEC_SEG_PTR,        // u32[n_tiles*(n_terms+1)]
     SEC_POSTINGS,       // u32[n_vecs*4]
+    SEC_DENSE_TERMS,    // u32[n_dense]     term id of every dense slot (slot s = bits 16*(s&1) of pair s/2)
+    SEC_DENSE,          // u32[n_tiles*(n_dense/2)*tile_docs]
     SEC_COUNT
 };
 
@@ -56,14 +68,15 @@ struct IndexHeader {
     uint32_t n_terms;
     uint32_t n_tiles;
     uint32_t max_weight;
-    uint32_t flags;
+    uint32_t n_dense;          // dense-head terms (even)
     uint64_t off[SEC_COUNT];   // byte offset of each section in the file
     uint64_t size[SEC_COUNT];  // byte size of each section
     uint64_t file_size;
     uint64_t reserved[3];
 };
 
-constexpr uint32_t kIndexVersion = 1;
+constexpr uint32_t kIndexVersion = 2;
+constexpr uint32_t kMaxDense = 32;
 constexpr uint32_t kDefaultTileDocs = 32768;
 constexpr uint32_t kMaxWeight = 65535;
 constexpr uint32_t kChunkPostings = 256;  // postings per chunk (64 lanes x uint4)
@@ -91,6 +104,9 @@ struct HostIndex {
     const char* doc_str = nullptr;
     const uint32_t* seg_ptr = nullptr;
     const uint32_t* postings = nullptr;
+    const uint32_t* dense_terms = nullptr;
+    const uint32_t* dense = nullptr;
+    std::vector<int8_t> dense_slot;  // term id -> dense slot, -1 = sparse term
 
     int open(const char* path);  // MSR_OK or error (message set)
     void close();
@@ -115,6 +131,13 @@ namespace msr {
 // implemented in msr_device.hip
 int device_attach(msr_index* ix, int device);  // upload the shard [shard_tile0, shard_tile0+shard_ntiles)
 void device_detach(msr_index* ix);
+
+// build options (msr_set_build_option)
+struct BuildOptions {
+    double dense_min_density = 0.4;  // a term is stored in the dense head when df >= this * n_docs
+    uint32_t dense_max_terms = 16;   // at most this many (<= kMaxDense); 0 disables the dense head
+};
+BuildOptions& build_options();
 
 int build_from_csr(const char* out_path, uint64_t n_docs, uint32_t n_terms, const uint64_t* doc_ptr,
                    const uint32_t* term_id, const uint32_t* weight, const char* const* doc_ids,

@@ -36,6 +36,11 @@ def auto_tile_docs(n_docs):
     return 32768
 
 
+def set_build_option(key, value):
+    """'dense_min_density' (default 0.4) / 'dense_max_terms' (default 16, 0 = no dense head) for later builds."""
+    check(lib().msr_set_build_option(key.encode(), float(value)))
+
+
 def build_index_from_jsonl(jsonl_dir, out_file=None, threads=16, tile_docs=0):
     """corpus_*.jsonl under `jsonl_dir` -> `<jsonl_dir>/index/msr.idx` (scripts/sparse_index.sh:14-15 layout)."""
     if out_file is None:
@@ -102,6 +107,7 @@ class SparseIndex:
         self.device = int(info.device)
         self.shard_tile0 = int(info.shard_tile0)
         self.shard_ntiles = int(info.shard_ntiles)
+        self.n_dense = int(info.n_dense)
 
     # ---- metadata
     def close(self):

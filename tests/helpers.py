@@ -5,7 +5,8 @@ import struct
 
 import numpy as np
 
-SECTIONS = ["term_off", "term_str", "term_sorted", "df", "maxw", "doc_off", "doc_str", "seg_ptr", "postings"]
+SECTIONS = ["term_off", "term_str", "term_sorted", "df", "maxw", "doc_off", "doc_str", "seg_ptr", "postings",
+            "dense_terms", "dense"]
 
 
 def read_index_file(path):
@@ -16,10 +17,11 @@ def read_index_file(path):
     assert magic == b"MSRIDX01", magic
     version, tile_docs = struct.unpack_from("<II", b, 8)
     n_docs, n_postings, n_vecs = struct.unpack_from("<QQQ", b, 16)
-    n_terms, n_tiles, max_weight, flags = struct.unpack_from("<IIII", b, 40)
-    off = struct.unpack_from("<9Q", b, 56)
-    size = struct.unpack_from("<9Q", b, 56 + 72)
-    (file_size,) = struct.unpack_from("<Q", b, 56 + 144)
+    n_terms, n_tiles, max_weight, n_dense = struct.unpack_from("<IIII", b, 40)
+    ns = len(SECTIONS)
+    off = struct.unpack_from(f"<{ns}Q", b, 56)
+    size = struct.unpack_from(f"<{ns}Q", b, 56 + 8 * ns)
+    (file_size,) = struct.unpack_from("<Q", b, 56 + 16 * ns)
     assert file_size == len(b)
     sec = {name: b[off[i] : off[i] + size[i]] for i, name in enumerate(SECTIONS)}
     term_off = np.frombuffer(sec["term_off"], dtype=np.uint64)
@@ -31,7 +33,9 @@ def read_index_file(path):
     seg_ptr = np.frombuffer(sec["seg_ptr"], dtype=np.uint32).reshape(n_tiles, n_terms + 1)
     postings = np.frombuffer(sec["postings"], dtype=np.uint32)
     return dict(version=version, tile_docs=tile_docs, n_docs=n_docs, n_postings=n_postings, n_vecs=n_vecs,
-                n_terms=n_terms, n_tiles=n_tiles, max_weight=max_weight, terms=terms, docs=docs,
+                n_terms=n_terms, n_tiles=n_tiles, max_weight=max_weight, terms=terms, docs=docs, n_dense=n_dense,
+                dense_terms=np.frombuffer(sec["dense_terms"], dtype=np.uint32),
+                dense=np.frombuffer(sec["dense"], dtype=np.uint32).reshape(n_tiles, n_dense // 2, tile_docs),
                 term_sorted=np.frombuffer(sec["term_sorted"], dtype=np.uint32),
                 df=np.frombuffer(sec["df"], dtype=np.uint32), maxw=np.frombuffer(sec["maxw"], dtype=np.uint32),
                 seg_ptr=seg_ptr, postings=postings)
@@ -57,6 +61,14 @@ def index_file_to_dense(ix):
             loc = (real & 0xFFFF).astype(np.int64)
             assert (np.diff(loc) > 0).all(), "ordinals ascend inside a segment"
             D[tile * ix["tile_docs"] + loc, t] += (real >> 16).astype(np.int64)
+    # dense head: slot s of pair s // 2 holds the weights of term dense_terms[s]; those terms have no segments
+    for s, t in enumerate(ix["dense_terms"]):
+        if t == 0xFFFFFFFF:
+            assert not ((ix["dense"][:, s // 2, :] >> (16 * (s & 1))) & 0xFFFF).any()
+            continue
+        assert not D[:, t].any(), "a dense-head term must not have inverted lists"
+        w = ((ix["dense"][:, s // 2, :] >> (16 * (s & 1))) & 0xFFFF).reshape(-1)[: ix["n_docs"]]
+        D[:, t] = w.astype(np.int64)
     return D
 
 

@@ -19,9 +19,16 @@ def m(built):
     return m
 
 
-def _case(m, tmp_path, n_docs, doc_nnz, nq, q_nnz, n_terms, seed, tile_docs, ks, doc_ids=None):
+def _case(m, tmp_path, n_docs, doc_nnz, nq, q_nnz, n_terms, seed, tile_docs, ks, doc_ids=None, dense_max=16,
+          dense_density=0.4):
     docs, (qp, qt, qw) = helpers.synth(n_docs, doc_nnz, nq, q_nnz, n_terms, seed)
-    path = m.build_index_from_csr(str(tmp_path / "c.idx"), *docs, n_terms, doc_ids=doc_ids, tile_docs=tile_docs)
+    m.set_build_option("dense_max_terms", dense_max)
+    m.set_build_option("dense_min_density", dense_density)
+    try:
+        path = m.build_index_from_csr(str(tmp_path / "c.idx"), *docs, n_terms, doc_ids=doc_ids, tile_docs=tile_docs)
+    finally:
+        m.set_build_option("dense_max_terms", 16)
+        m.set_build_option("dense_min_density", 0.4)
     oix, _ = helpers.taat_oracle(docs, n_terms, doc_ids)
     with m.SparseIndex(path, device=0) as ix:
         for k in ks:
@@ -31,9 +38,11 @@ def _case(m, tmp_path, n_docs, doc_nnz, nq, q_nnz, n_terms, seed, tile_docs, ks,
 
 
 @pytest.mark.parametrize("tile_docs", [4096, 8192, 16384, 32768])
-def test_single_and_multi_tile(m, tmp_path, tile_docs):
-    # 20k docs: 5 / 3 / 2 / 1 tiles, last tile ragged
-    _case(m, tmp_path, 20000, 64, 200, 40, 5000, seed=21, tile_docs=tile_docs, ks=[1, 10, 100])
+@pytest.mark.parametrize("dense_max,density", [(16, 0.4), (0, 0.4), (32, 0.02), (5, 0.1)])
+def test_single_and_multi_tile(m, tmp_path, tile_docs, dense_max, density):
+    # 20k docs: 5 / 3 / 2 / 1 tiles, last tile ragged; with / without / with a large / with an odd-sized dense head
+    _case(m, tmp_path, 20000, 64, 200, 40, 5000, seed=21, tile_docs=tile_docs, ks=[1, 10, 100], dense_max=dense_max,
+          dense_density=density)
 
 
 def test_flickr_shape_c2(m, tmp_path):
@@ -123,7 +132,7 @@ def test_overflow_is_refused(m, tmp_path):
     dw = np.array([65535, 65535], dtype=np.uint32)
     path = m.build_index_from_csr(str(tmp_path / "o.idx"), dp, dt, dw, 2, tile_docs=4096)
     with m.SparseIndex(path, device=0) as ix:
-        with pytest.raises(Exception, match="OVERFLOW"):
+        with pytest.raises(Exception, match="OVERFLOW|RANGE"):
             ix.search_csr(np.array([0, 1]), np.array([0]), np.array([70000]), 1)
         ords, f32, u32, n = ix.search_csr(np.array([0, 1]), np.array([0]), np.array([65535]), 1)
         assert n[0] == 1 and u32[0, 0] == 65535 * 65535 and f32[0, 0] == np.float32(65535 * 65535)
