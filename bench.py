@@ -114,7 +114,7 @@ def timed_steps(batch, k, steps, warmup, ranks, sharded=False):
     if os.environ.get("MSR_DEBUG_FLAGS"):
         st = batch.debug_stamps().astype(np.float64)
         if st.sum() > 0:
-            names = ["zero", "stage", "stream", "wait", "maxima", "cand", "rank", "-"]
+            names = ["init", "stage", "stream", "wait", "maxima", "cand", "rank", "resolve"]
             log("[bench] wave-0 phase shares: " + ", ".join(f"{n}={v / st.sum():.3f}" for n, v in zip(names, st))
                 + f"; cycles/WG-launch total={st.sum() / max(calls + warmup, 1):.3e}")
     return ranks.max(dt), score_ms / max(calls, 1), merge_ms / max(calls, 1)
@@ -300,7 +300,9 @@ def main():
     ap.add_argument("--tile-docs", type=int, default=0)
     ap.add_argument("--c4-docs", type=int, default=1_000_000)
     ap.add_argument("--c4-queries", type=int, default=10_000)
-    ap.add_argument("--c4-tile-docs", type=int, default=32768)
+    ap.add_argument("--c4-tile-docs", type=int, default=0)
+    ap.add_argument("--dense-max", type=int, default=-1, help="index build option dense_max_terms (-1: library default)")
+    ap.add_argument("--dense-density", type=float, default=-1.0, help="index build option dense_min_density")
     ap.add_argument("--no-c4", action="store_true", help="skip the 1 M-doc extra object")
     ap.add_argument("--only-c4", action="store_true", help="(profiling) run only the 1 M-doc workload")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline / parity sample")
@@ -312,6 +314,11 @@ def main():
     ranks = Ranks(args.gpus)
     import mllm_sparse_retrieval_amd as m  # raises if libmsr.so is missing: there is no fallback scorer
     from mllm_sparse_retrieval_amd import workloads as wlmod
+
+    if args.dense_max >= 0:
+        m.set_build_option("dense_max_terms", args.dense_max)
+    if args.dense_density >= 0:
+        m.set_build_option("dense_min_density", args.dense_density)
 
     out = {}
     if not args.only_c4:

@@ -69,7 +69,7 @@ typedef struct msr_info {
 
 /* ---- index build: replaces scripts/sparse_index.sh:12-18 (pyserini.index.lucene --impact --pretokenized) ----
  * Reads every *.jsonl / *.json file of `jsonl_dir` (lines {"id":…,"content":…,"vector":{tok:int}} as written by
- * src/encode.py:351-359,426) and writes one index file. tile_docs = 0 picks the default (32768). */
+ * src/encode.py:351-359,426) and writes one index file. tile_docs = 0 picks the default (8192); supported: 4096, 8192, 12288, 16384, 32768. */
 int msr_index_build(const char* jsonl_dir, const char* out_path, int threads, uint32_t tile_docs);
 
 /* Process-wide build options (set before building; not thread-safe):

@@ -143,11 +143,11 @@ struct ScoreArgs {
 
 // LDS carve (bytes). The staging arrays of the streaming phase and the candidate keys of the select phase are
 // never live together, so they share one region.
-template <int TILE_DOCS, int NT>
+template <int TILE_DOCS, int NT, int CAND>
 struct TileLds {
     static constexpr int kAcc = TILE_DOCS * 4;
     static constexpr int kStage = kQtBlock * 4 * 3 + (kQtBlock + 4) * 4 + 8 * 4;  // seg_start/len/w, pref, wsum
-    static constexpr int kCand = kCandCap * 8;
+    static constexpr int kCand = CAND * 8;
     static constexpr int kUnion = (kStage > kCand ? kStage : kCand);
     static constexpr int kTmax = NT * 4 + 64 * 4;  // per-thread maxima (k > waves) + per-wave maxima
     static constexpr int kTotal = kAcc + kUnion + kTmax + (int)sizeof(SelectScratch);
@@ -156,13 +156,13 @@ struct TileLds {
 __device__ __forceinline__ uint32_t rfl(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
 __device__ __forceinline__ uint32_t rdl(uint32_t v, uint32_t l) { return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)l); }
 
-template <int TILE_DOCS, int NT, int MIN_WAVES, bool DBG>
+// <docs per tile, threads, 1-KiB chunk loads per register bank, min waves per SIMD, candidate-key capacity (>= k), diag>
+template <int TILE_DOCS, int NT, int U, int MIN_WAVES, int CAND, bool DBG>
 __global__ __launch_bounds__(NT, MIN_WAVES) void score_tiles(const ScoreArgs a) {
     constexpr int NW = NT / 64;
-    constexpr int U = 8;  // 1-KiB chunk loads in flight per wave
     static_assert(TILE_DOCS % (4 * NT) == 0, "tile must be a multiple of 4*NT");
     static_assert(NT >= kQtBlock, "the staging scan uses the first 256 threads");
-    using L = TileLds<TILE_DOCS, NT>;
+    using L = TileLds<TILE_DOCS, NT, CAND>;
 
     __shared__ __attribute__((aligned(16))) uint8_t lds[L::kTotal];
     uint32_t* const acc = reinterpret_cast<uint32_t*>(lds);
@@ -185,13 +185,14 @@ __global__ __launch_bounds__(NT, MIN_WAVES) void score_tiles(const ScoreArgs a) 
     // diagnostic build only: wave 0 stamps s_memtime at phase boundaries and adds the deltas to a side buffer
     long long t_prev = 0;
     auto stamp = [&](int slot) {
-        if (DBG && (a.dbg & 8u) && a.stamps && tid == 0) {
+        if (DBG && (a.dbg & 8u) && a.stamps && tid == 0 && (blockIdx.x & 63u) == 0) {  // 1 workgroup in 64
             const long long now = clock64();
             if (slot >= 0) atomicAdd(&a.stamps[slot], (unsigned long long)(now - t_prev));
             t_prev = now;
         }
     };
     stamp(-1);
+    if (DBG && (a.dbg & 128u)) return;  // ablation: workgroup launch cost only
     const uint32_t tile_l = blockIdx.x / a.nq;  // tile-major: neighbours in dispatch order share the tile
     const uint32_t q = blockIdx.x % a.nq;
     const uint32_t tile_g = a.tile0 + tile_l;
@@ -323,6 +324,8 @@ __global__ __launch_bounds__(NT, MIN_WAVES) void score_tiles(const ScoreArgs a) 
         // dense head terms and the one-chunk tail terms evenly. The (term, offset) of a wave's next 64 chunks is
         // resolved lane-parallel (one binary search per lane), then broadcast chunk by chunk with v_readlane, so
         // the inner loop is scalar control + one 16-byte load and four LDS atomics per lane.
+        stamp(1);  // staging: segment table + chunk-count scan
+        if (DBG && (a.dbg & 64u)) break;  // ablation: stop after staging
         const uint32_t total = rfl(pref[kQtBlock]);
         const uint32_t c_end = total > wave ? (total - wave + NW - 1) / NW : 0u;  // chunks of this wave
         for (uint32_t cb = 0; cb < c_end; cb += 64) {
@@ -343,6 +346,8 @@ __global__ __launch_bounds__(NT, MIN_WAVES) void score_tiles(const ScoreArgs a) 
                 m_n = min((uint32_t)kChunkVecs, seg_len[lo] - voff);
                 m_w = seg_w[lo];
             }
+            stamp(7);  // lane-parallel chunk resolution (binary search)
+            if (DBG && (a.dbg & 256u)) break;  // ablation: stop after the first chunk resolution
             const uint32_t nchunk = min(64u, c_end - cb);
             // Software pipeline, two register banks of U chunks: the next bank's 1-KiB loads are in flight while
             // the current bank's LDS atomics issue. Loads are unconditional (lanes past a chunk's end, and chunk
@@ -416,38 +421,36 @@ __global__ __launch_bounds__(NT, MIN_WAVES) void score_tiles(const ScoreArgs a) 
         const uint4 x = a4[r * NT + tid];
         mymax = max(max(mymax, max(x.x, x.y)), max(x.z, x.w));
     }
-    {
-        const uint32_t wm = wave_max_u32(mymax);
-        if (lane == 0) wmax[wave] = wm;
-        if (k > NW) tmax[tid] = mymax;
-    }
+    // ---- tau0: a lower bound with at least k accumulators at or above it = the k-th largest GROUP maximum.
+    //   k <= 64 : 64 groups of NT/64 consecutive threads (log2(NT/64) shuffle steps), then every wave bisects the
+    //             64 group maxima with ballots (no further barrier);
+    //   k >  64 : groups are single threads (NT maxima, NT/64 per lane of wave 0), one more barrier.
+    constexpr int G = NT / 64;  // threads per group
+    uint32_t gm = mymax;
+#pragma unroll
+    for (int o = 1; o < G; o <<= 1) gm = max(gm, (uint32_t)__shfl_xor(gm, o, 64));
+    if ((lane & (G - 1)) == 0) wmax[tid / G] = gm;
+    if (k > 64) tmax[tid] = mymax;
     __syncthreads();
 
-    // ---- tau0: a lower bound with at least k accumulators at or above it.
-    //   k <= NW : the k-th largest WAVE maximum (every wave ranks the NW maxima by counting, no further barrier)
-    //   k >  NW : the k-th largest THREAD maximum (wave 0 bisects on ballots)
-    uint32_t tau0, smax;
+    uint32_t tau0 = 1, smax;
     {
-        const uint32_t v = lane < (uint32_t)NW ? wmax[lane] : 0u;
-        uint32_t rank = 0, m = 0;
-#pragma unroll
-        for (int j = 0; j < NW; ++j) {
-            const uint32_t o = rdl(v, j);
-            rank += (o > v) || (o == v && (uint32_t)j < lane);
-            m = max(m, o);
+        const uint32_t v = wmax[lane];  // 64 group maxima, one per lane, in every wave
+        smax = wave_max_u32(v);
+        if (smax == 0) {  // nothing matched in this tile
+            for (int i = tid; i < k; i += NT) out[i] = 0;
+            return;
         }
-        smax = m;
-        tau0 = 1;
-        if (k <= NW) {
-            const unsigned long long mk = __ballot(lane < (uint32_t)NW && rank == (uint32_t)(k - 1));
-            tau0 = max(rdl(v, (uint32_t)(__ffsll((long long)mk) - 1) & 63u), 1u);
+        if (k <= 64) {
+            uint32_t tau = 0;
+            for (int bit = 31 - __clz(smax); bit >= 0; --bit) {
+                const uint32_t t2 = tau | (1u << bit);
+                if (__popcll(__ballot(v >= t2)) >= k) tau = t2;
+            }
+            tau0 = max(tau, 1u);
         }
     }
-    if (smax == 0) {  // nothing matched in this tile
-        for (int i = tid; i < k; i += NT) out[i] = 0;
-        return;
-    }
-    if (k > NW && k <= NT) {
+    if (k > 64 && k <= NT) {
         if (wave == 0) {
             uint32_t mine[NW];
 #pragma unroll
@@ -477,7 +480,7 @@ __global__ __launch_bounds__(NT, MIN_WAVES) void score_tiles(const ScoreArgs a) 
                 if (sc4[e] >= tau0) {
                     const uint32_t local = 4 * (r * NT + tid) + e;
                     const uint32_t pos = atomicAdd(&ss.n_cand, 1u);
-                    if (pos < kCandCap)
+                    if (pos < CAND)
                         cand[pos] = ((uint64_t)sc4[e] << 32) | (uint64_t)(0xFFFFFFFFu - (uint32_t)(doc0 + local));
                 }
         }
@@ -486,7 +489,7 @@ __global__ __launch_bounds__(NT, MIN_WAVES) void score_tiles(const ScoreArgs a) 
     stamp(5);  // candidate collection
     uint32_t n_cand = ss.n_cand;
 
-    if (n_cand > kCandCap) {
+    if (n_cand > CAND) {
         // ---- fallback: bisection for the k-th largest (score, ordinal) key of the whole tile.
         // local key = score << 16 | (0xFFFF - local ordinal): unique, so exactly min(k, #positive) survive.
         __syncthreads();  // everyone has read n_cand
@@ -522,13 +525,13 @@ __global__ __launch_bounds__(NT, MIN_WAVES) void score_tiles(const ScoreArgs a) 
                 const uint64_t key = sc4[e] ? (((uint64_t)sc4[e] << 16) | (0xFFFFu - local)) : 0ull;
                 if (key && key >= tau) {
                     const uint32_t pos = atomicAdd(&ss.n_cand, 1u);
-                    if (pos < kCandCap)
+                    if (pos < CAND)
                         cand[pos] = ((uint64_t)sc4[e] << 32) | (uint64_t)(0xFFFFFFFFu - (uint32_t)(doc0 + local));
                 }
             }
         }
         __syncthreads();
-        n_cand = min(ss.n_cand, (uint32_t)kCandCap);  // == min(k, #positive) <= kCandCap by construction
+        n_cand = min(ss.n_cand, (uint32_t)CAND);  // == min(k, #positive) <= CAND by construction
     }
     rank_and_emit<NT>(cand, (int)n_cand, k, out);
     stamp(6);  // ranking + output
@@ -637,21 +640,23 @@ static int launch_score(hipStream_t st, uint32_t tile_docs, uint32_t ntiles, con
         return MSR_E_RANGE;
     }
     switch (tile_docs) {
-        // <tile docs, threads, min waves/SIMD>: 32768 -> 1 workgroup/CU (16 waves), 16384 -> 2/CU (16 waves),
-        // 8192 -> 3/CU (12 waves), 4096 -> 4/CU (16 waves)
-#define MSR_LAUNCH(T, N, W)                                                                                   \
+#define MSR_LAUNCH(T, N, UU, W)                                                                               \
     if (a.dbg)                                                                                                \
-        hipLaunchKernelGGL((score_tiles<T, N, W, true>), dim3((uint32_t)blocks), dim3(N), 0, st, a);          \
+        hipLaunchKernelGGL((score_tiles<T, N, UU, W, 1024, true>), dim3((uint32_t)blocks), dim3(N), 0, st, a);  \
+    else if (a.k <= 512)                                                                                      \
+        hipLaunchKernelGGL((score_tiles<T, N, UU, W, 512, false>), dim3((uint32_t)blocks), dim3(N), 0, st, a);  \
     else                                                                                                      \
-        hipLaunchKernelGGL((score_tiles<T, N, W, false>), dim3((uint32_t)blocks), dim3(N), 0, st, a);         \
+        hipLaunchKernelGGL((score_tiles<T, N, UU, W, 1024, false>), dim3((uint32_t)blocks), dim3(N), 0, st, a); \
     break;
-        case 32768: MSR_LAUNCH(32768, 1024, 4)
-        case 16384: MSR_LAUNCH(16384, 512, 4)
-        case 8192: MSR_LAUNCH(8192, 256, 3)
-        case 4096: MSR_LAUNCH(4096, 256, 4)
+        // LDS per workgroup = 4 B x tile + 4-8 KiB candidates + maxima -> workgroups (waves) per CU:
+        case 32768: MSR_LAUNCH(32768, 1024, 8, 4)  // 1 (16)
+        case 16384: MSR_LAUNCH(16384, 512, 8, 4)   // 2 (16)
+        case 12288: MSR_LAUNCH(12288, 512, 4, 6)   // 3 (24) with k <= 512
+        case 8192: MSR_LAUNCH(8192, 512, 4, 8)     // 4 (32) with k <= 512
+        case 4096: MSR_LAUNCH(4096, 256, 4, 8)     // 7 (28)
 #undef MSR_LAUNCH
         default:
-            set_error("no kernel instance for tile_docs=%u (supported: 4096, 8192, 16384, 32768)", tile_docs);
+            set_error("no kernel instance for tile_docs=%u (supported: 4096, 8192, 12288, 16384, 32768)", tile_docs);
             return MSR_E_RANGE;
     }
     HIP_TRY(hipGetLastError());
@@ -680,9 +685,9 @@ int device_attach(msr_index* ix, int device) {
     }
     const IndexHeader* h = ix->host.h;
     switch (h->tile_docs) {
-        case 4096: case 8192: case 16384: case 32768: break;
+        case 4096: case 8192: case 12288: case 16384: case 32768: break;
         default:
-            set_error("index tile_docs=%u has no kernel instance (supported: 4096, 8192, 16384, 32768)", h->tile_docs);
+            set_error("index tile_docs=%u has no kernel instance (supported: 4096, 8192, 12288, 16384, 32768)", h->tile_docs);
             return MSR_E_RANGE;
     }
     DeviceIndex* d = new (std::nothrow) DeviceIndex;

@@ -77,7 +77,7 @@ struct IndexHeader {
 
 constexpr uint32_t kIndexVersion = 2;
 constexpr uint32_t kMaxDense = 32;
-constexpr uint32_t kDefaultTileDocs = 32768;
+constexpr uint32_t kDefaultTileDocs = 8192;
 constexpr uint32_t kMaxWeight = 65535;
 constexpr uint32_t kChunkPostings = 256;  // postings per chunk (64 lanes x uint4)
 
