@@ -579,40 +579,58 @@ __global__ __launch_bounds__(NT) void merge_lists(const MergeArgs a) {
         __syncthreads();
         n_cand = ss.n_cand;
     } else {
-        // bisection for the k-th largest key, re-reading the lists from L2 each step
-        uint64_t m = 0;
-        for (uint32_t i = tid; i < n_items; i += NT) {
-            const uint64_t key = key_at(i);
-            m = key > m ? key : m;
-        }
-        m = wave_max_u64(m);
-        if (lane == 0) wmax[wave] = m;
-        __syncthreads();
-        m = 0;
-        for (int w = 0; w < NT / 64; ++w) m = wmax[w] > m ? wmax[w] : m;
-        uint64_t tau = 0;
-        if (m) {
-            int step = 0;
-            for (int bit = 63 - __clzll((long long)m); bit >= 0; --bit, ++step) {
-                const uint64_t t2 = tau | (1ull << bit);
-                uint32_t c = 0;
-                for (uint32_t i = tid; i < n_items; i += NT) c += key_at(i) >= t2;
-                c = wave_sum_u32(c);
-                if (lane == 0 && c) atomicAdd(&ss.cnt[step], c);  // at most 64 steps: one slot each
-                __syncthreads();
-                if (ss.cnt[step] >= (uint32_t)k) tau = t2;
+        // More keys than the LDS buffer holds. Every list is sorted best-first, so the k-th largest of the lists'
+        // HEAD keys is a lower bound on the global k-th key (when there are at least k non-empty lists); keys at or
+        // above it are few. If they do not fit either (or there are fewer than k lists), bisect over all keys.
+        auto bisect_kth = [&](uint32_t n, auto key_of) -> uint64_t {  // k-th largest of n keys (0 if fewer than k > 0)
+            uint64_t m = 0;
+            for (uint32_t i = tid; i < n; i += NT) {
+                const uint64_t key = key_of(i);
+                m = key > m ? key : m;
             }
-        }
-        __syncthreads();
-        for (uint32_t i = tid; i < n_items; i += NT) {
-            const uint64_t key = key_at(i);
-            if (key && key >= tau) {
-                const uint32_t pos = atomicAdd(&ss.n_cand, 1u);
-                if (pos < kCandCap) cand[pos] = key;
+            m = wave_max_u64(m);
+            __syncthreads();  // previous users of wmax / cnt are done
+            if (lane == 0) wmax[wave] = m;
+            if (tid < 64) ss.cnt[tid] = 0;
+            __syncthreads();
+            m = 0;
+            for (int w = 0; w < NT / 64; ++w) m = wmax[w] > m ? wmax[w] : m;
+            uint64_t tau = 0;
+            if (m) {
+                int step = 0;
+                for (int bit = 63 - __clzll((long long)m); bit >= 0; --bit, ++step) {
+                    const uint64_t t2 = tau | (1ull << bit);
+                    uint32_t c = 0;
+                    for (uint32_t i = tid; i < n; i += NT) c += key_of(i) >= t2;
+                    c = wave_sum_u32(c);
+                    if (lane == 0 && c) atomicAdd(&ss.cnt[step], c);  // at most 64 steps: one slot each
+                    __syncthreads();
+                    if (ss.cnt[step] >= (uint32_t)k) tau = t2;
+                }
             }
+            return tau;
+        };
+        auto collect = [&](uint64_t tau) {
+            __syncthreads();
+            if (tid == 0) ss.n_cand = 0;
+            __syncthreads();
+            for (uint32_t i = tid; i < n_items; i += NT) {
+                const uint64_t key = key_at(i);
+                if (key && key >= tau) {
+                    const uint32_t pos = atomicAdd(&ss.n_cand, 1u);
+                    if (pos < kCandCap) cand[pos] = key;
+                }
+            }
+            __syncthreads();
+            return ss.n_cand;
+        };
+        uint32_t got = kCandCap + 1;
+        if (a.n_lists >= (uint32_t)k) {
+            const uint64_t tau_heads = bisect_kth(a.n_lists, [&](uint32_t l) { return key_at(l * a.k); });
+            if (tau_heads) got = collect(tau_heads);
         }
-        __syncthreads();
-        n_cand = min(ss.n_cand, (uint32_t)kCandCap);
+        if (got > kCandCap) got = collect(bisect_kth(n_items, key_at));  // exactly min(k, #keys) <= kCandCap survive
+        n_cand = min(got, (uint32_t)kCandCap);
     }
     rank_and_emit<NT>(cand, (int)n_cand, k, res);
     __syncthreads();

@@ -267,3 +267,9 @@ def test_full_size_properties_c4(m, tmp_path):
     s = 200
     want = oix.search(qp[: s + 1], qt[: qp[s]], qw[: qp[s]], 10, threads=16)
     helpers.assert_same_results((o[:s], f[:s], u[:s], n[:s]), want, 10)
+
+
+def test_merge_of_many_tile_lists(m, tmp_path):
+    # 37 tiles x k=100 = 3 700 partial keys per query: more than the merge kernel's LDS buffer, so the list-head
+    # threshold path (and, with k = 1000 > #lists, the full bisection) is exercised
+    _case(m, tmp_path, 150000, 16, 120, 30, 2000, seed=77, tile_docs=4096, ks=[10, 100, 1000])
