@@ -214,6 +214,22 @@ def run_headline(args, ranks, m, wlmod):
             out["cpu_baseline"] = cb
             out["parity"] = par
             out["speedup_vs_cpu"] = round(out["value"] / cb["value"], 1)
+        if ranks.world == 1:
+            # PCIe-inclusive figures (never `value`): host CSR in -> host results out through msr_search_csr, and the
+            # reference's own call shape of 4 queries per batch_search call (scripts/search_sparse.sh:16)
+            ix.search_csr(qp, qt, qw, wl.k)
+            t0 = time.perf_counter()
+            ix.search_csr(qp, qt, qw, wl.k)
+            e2e = time.perf_counter() - t0
+            q4 = (qp[:5] - qp[0]), qt[: qp[4]], qw[: qp[4]]
+            ix.search_csr(*q4, wl.k)
+            t0 = time.perf_counter()
+            for _ in range(50):
+                ix.search_csr(*q4, wl.k)
+            small = (time.perf_counter() - t0) / 50
+            out["host_inclusive"] = {"queries_per_s_one_call": round(nq / e2e, 1),
+                                     "ms_per_call_4_queries": round(small * 1e3, 4),
+                                     "queries_per_s_4_per_call": round(4 / small, 1)}
     batch.close()
     ix.close()
     try:

@@ -142,6 +142,18 @@ int msr_comm_init(msr_index* ix, int n_ranks, int rank, const char id[MSR_COMM_I
 int msr_batch_search_sharded(msr_batch* b, int k);
 int msr_comm_destroy(msr_index* ix);
 
+/* Term-range shards (the north star's partition; exact protocol of DESIGN.md §6): the batch holds only the query terms
+ * of term range `shard` of `n_shards` (ranges are contiguous in term id and balanced by postings). Search = dump the
+ * partial accumulators, ncclReduceScatter(sum) them into doc ranges, select, all-gather, merge. The handle must hold
+ * every doc tile (msr_index_open) and the communicator's rank / size must equal shard / n_shards. */
+int msr_batch_create_termshard(msr_index* ix, const int64_t* q_ptr, const int32_t* q_term, const int32_t* q_w, int nq,
+                               int kmax, uint32_t flags, int shard, int n_shards, msr_batch** out);
+int msr_batch_search_termshard(msr_batch* b, int k);
+/* The same protocol for `n_shards` logical term shards played on one GPU (sums in place instead of RCCL). */
+int msr_search_termshard_emulated(msr_index* ix, const int64_t* q_ptr, const int32_t* q_term, const int32_t* q_w, int nq,
+                                  int k, uint32_t flags, int n_shards, uint32_t* out_doc_ord, float* out_score,
+                                  uint32_t* out_score_u32, int32_t* out_n);
+
 /* Merge `n_lists` per-shard result lists (each [nq][k] as written by msr_batch_fetch) on the device of `ix`
  * with the same tie rule; used by the host-side exchange (torch.distributed all_gather) and by tests. */
 int msr_merge_lists(msr_index* ix, int n_lists, int nq, int k, const uint32_t* doc_ord, const uint32_t* score_u32,

@@ -70,6 +70,9 @@ SYMBOLS = [
     ("msr_comm_init", _I, [_VP, _I, _I, _VP]),
     ("msr_batch_search_sharded", _I, [_VP, _I]),
     ("msr_comm_destroy", _I, [_VP]),
+    ("msr_batch_create_termshard", _I, [_VP, _VP, _VP, _VP, _I, _I, _U32, _I, _I, C.POINTER(_VP)]),
+    ("msr_batch_search_termshard", _I, [_VP, _I]),
+    ("msr_search_termshard_emulated", _I, [_VP, _VP, _VP, _VP, _I, _I, _U32, _I, _VP, _VP, _VP, _VP]),
     ("msr_merge_lists", _I, [_VP, _I, _I, _I, _VP, _VP, _VP, _VP, _VP, _VP, _VP]),
     ("msr_synth_vectors", _I, [_U64, _U32, _U32, C.c_double, _U64, _I, _VP, _VP, _VP]),
     ("msr_last_error", _CP, []),

@@ -83,6 +83,9 @@ __device__ __forceinline__ uint64_t wave_max_u64(uint64_t v) {
     return v;
 }
 
+__device__ __forceinline__ uint32_t rfl(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+__device__ __forceinline__ uint32_t rdl(uint32_t v, uint32_t l) { return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)l); }
+
 // Rank-by-counting over `n` UNIQUE non-zero keys in LDS: key with rank r < k goes to out[r]; slots [n, k) get 0.
 template <int NT>
 __device__ __forceinline__ void rank_and_emit(const uint64_t* cand, int n, int k, uint64_t* __restrict__ out) {
@@ -135,8 +138,16 @@ struct ScoreArgs {
     uint32_t vec_base;
     uint32_t n_terms;
     uint32_t tile0;            // first (global) tile of the shard
-    uint32_t nq;
+    uint32_t nq;               // queries of the batch (row stride of `part`)
+    uint32_t q0;               // this launch scores queries [q0, q0 + qn)
+    uint32_t qn;
     uint32_t k;
+    // term-sharded search (MODE 1): instead of selecting, the accumulator tile is written (or added) to
+    // dump[((g * qn + (q - q0)) * tpr + t) * TILE_DOCS + i] with g = tile / tpr, t = tile % tpr  — the layout whose
+    // G equal chunks are the doc ranges that ncclReduceScatter hands to the G ranks
+    uint32_t* dump;
+    uint32_t tpr;              // tiles per rank = ceil(n_tiles / G)
+    uint32_t dump_add;         // 1: dump[...] += tile (single-GPU emulation of the reduction), 0: store
     uint32_t dbg;              // MSR_DEBUG_FLAGS (timing ablations only; results are wrong when bits 0-2 are set)
     unsigned long long* stamps;  // [8] summed s_memtime deltas of wave 0 per phase (dbg bit 3), else null
 };
@@ -153,11 +164,140 @@ struct TileLds {
     static constexpr int kTotal = kAcc + kUnion + kTmax + (int)sizeof(SelectScratch);
 };
 
-__device__ __forceinline__ uint32_t rfl(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
-__device__ __forceinline__ uint32_t rdl(uint32_t v, uint32_t l) { return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)l); }
+
+// Exact top-k of one accumulator tile held in LDS (shared by score_tiles and select_tiles).
+// Thread `tid` owns vec r*NT + tid of the accumulators in round r (conflict-free ds_read_b128); the accumulators are
+// re-read from LDS in every pass instead of being held in registers. Writes k keys best-first (0 = empty slot).
+template <int TILE_DOCS, int NT, int CAND, class Stamp>
+__device__ __forceinline__ void tile_select(const uint4* a4, uint64_t* cand, uint32_t* tmax, uint32_t* wmax,
+                                            SelectScratch& ss, int rounds, uint64_t doc0, int k,
+                                            uint64_t* __restrict__ out, Stamp stamp) {
+    constexpr int NW = NT / 64;
+    const uint32_t tid = threadIdx.x;
+    const uint32_t lane = tid & 63;
+    const uint32_t wave = rfl(tid >> 6);
+    uint32_t mymax = 0;
+    for (int r = 0; r < rounds; ++r) {
+        const uint4 x = a4[r * NT + tid];
+        mymax = max(max(mymax, max(x.x, x.y)), max(x.z, x.w));
+    }
+    // ---- tau0: a lower bound with at least k accumulators at or above it = the k-th largest GROUP maximum.
+    //   k <= 64 : 64 groups of NT/64 consecutive threads (log2(NT/64) shuffle steps), then every wave bisects the
+    //             64 group maxima with ballots (no further barrier);
+    //   k >  64 : groups are single threads (NT maxima, NT/64 per lane of wave 0), one more barrier.
+    constexpr int G = NT / 64;  // threads per group
+    uint32_t gm = mymax;
+#pragma unroll
+    for (int o = 1; o < G; o <<= 1) gm = max(gm, (uint32_t)__shfl_xor(gm, o, 64));
+    if ((lane & (G - 1)) == 0) wmax[tid / G] = gm;
+    if (k > 64) tmax[tid] = mymax;
+    __syncthreads();
+
+    uint32_t tau0 = 1, smax;
+    {
+        const uint32_t v = wmax[lane];  // 64 group maxima, one per lane, in every wave
+        smax = wave_max_u32(v);
+        if (smax == 0) {  // nothing matched in this tile
+            for (int i = tid; i < k; i += NT) out[i] = 0;
+            return;
+        }
+        if (k <= 64) {
+            uint32_t tau = 0;
+            for (int bit = 31 - __clz(smax); bit >= 0; --bit) {
+                const uint32_t t2 = tau | (1u << bit);
+                if (__popcll(__ballot(v >= t2)) >= k) tau = t2;
+            }
+            tau0 = max(tau, 1u);
+        }
+    }
+    if (k > 64 && k <= NT) {
+        if (wave == 0) {
+            uint32_t mine[NW];
+#pragma unroll
+            for (int i = 0; i < NW; ++i) mine[i] = tmax[i * 64 + lane];
+            uint32_t tau = 0;
+            for (int bit = 31 - __clz(smax); bit >= 0; --bit) {
+                const uint32_t t2 = tau | (1u << bit);
+                uint32_t c = 0;
+#pragma unroll
+                for (int i = 0; i < NW; ++i) c += (uint32_t)__popcll(__ballot(mine[i] >= t2));
+                if (c >= (uint32_t)k) tau = t2;
+            }
+            if (lane == 0) ss.tau0 = max(tau, 1u);
+        }
+        __syncthreads();
+        tau0 = ss.tau0;
+    }
+
+    stamp(4);  // thread / wave maxima, tau0
+    // ---- candidates: accumulators >= tau0 as unique global keys (score << 32 | ~ordinal)
+    if (mymax >= tau0) {
+        for (int r = 0; r < rounds; ++r) {
+            const uint4 x = a4[r * NT + tid];
+            const uint32_t sc4[4] = {x.x, x.y, x.z, x.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (sc4[e] >= tau0) {
+                    const uint32_t local = 4 * (r * NT + tid) + e;
+                    const uint32_t pos = atomicAdd(&ss.n_cand, 1u);
+                    if (pos < CAND)
+                        cand[pos] = ((uint64_t)sc4[e] << 32) | (uint64_t)(0xFFFFFFFFu - (uint32_t)(doc0 + local));
+                }
+        }
+    }
+    __syncthreads();
+    stamp(5);  // candidate collection
+    uint32_t n_cand = ss.n_cand;
+
+    if (n_cand > CAND) {
+        // ---- fallback: bisection for the k-th largest (score, ordinal) key of the whole tile.
+        // local key = score << 16 | (0xFFFF - local ordinal): unique, so exactly min(k, #positive) survive.
+        __syncthreads();  // everyone has read n_cand
+        if (tid == 0) ss.n_cand = 0;
+        const int top = 16 + (32 - __clz(smax));  // bits in use (<= 48 < 64 counter slots)
+        uint64_t tau = 0;
+        int step = 0;
+        for (int bit = top - 1; bit >= 0; --bit, ++step) {
+            const uint64_t t2 = tau | (1ull << bit);
+            uint32_t c = 0;
+            for (int r = 0; r < rounds; ++r) {
+                const uint4 x = a4[r * NT + tid];
+                const uint32_t sc4[4] = {x.x, x.y, x.z, x.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const uint32_t local = 4 * (r * NT + tid) + e;
+                    const uint64_t key = sc4[e] ? (((uint64_t)sc4[e] << 16) | (0xFFFFu - local)) : 0ull;
+                    c += key >= t2;
+                }
+            }
+            c = wave_sum_u32(c);
+            if (lane == 0 && c) atomicAdd(&ss.cnt[step], c);
+            __syncthreads();
+            if (ss.cnt[step] >= (uint32_t)k) tau = t2;
+        }
+        __syncthreads();
+        for (int r = 0; r < rounds; ++r) {
+            const uint4 x = a4[r * NT + tid];
+            const uint32_t sc4[4] = {x.x, x.y, x.z, x.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const uint32_t local = 4 * (r * NT + tid) + e;
+                const uint64_t key = sc4[e] ? (((uint64_t)sc4[e] << 16) | (0xFFFFu - local)) : 0ull;
+                if (key && key >= tau) {
+                    const uint32_t pos = atomicAdd(&ss.n_cand, 1u);
+                    if (pos < CAND)
+                        cand[pos] = ((uint64_t)sc4[e] << 32) | (uint64_t)(0xFFFFFFFFu - (uint32_t)(doc0 + local));
+                }
+            }
+        }
+        __syncthreads();
+        n_cand = min(ss.n_cand, (uint32_t)CAND);  // == min(k, #positive) <= CAND by construction
+    }
+    rank_and_emit<NT>(cand, (int)n_cand, k, out);
+}
 
 // <docs per tile, threads, 1-KiB chunk loads per register bank, min waves per SIMD, candidate-key capacity (>= k), diag>
-template <int TILE_DOCS, int NT, int U, int MIN_WAVES, int CAND, bool DBG>
+template <int TILE_DOCS, int NT, int U, int MIN_WAVES, int CAND, bool DBG, int MODE = 0>
 __global__ __launch_bounds__(NT, MIN_WAVES) void score_tiles(const ScoreArgs a) {
     constexpr int NW = NT / 64;
     static_assert(TILE_DOCS % (4 * NT) == 0, "tile must be a multiple of 4*NT");
@@ -193,8 +333,8 @@ __global__ __launch_bounds__(NT, MIN_WAVES) void score_tiles(const ScoreArgs a) 
     };
     stamp(-1);
     if (DBG && (a.dbg & 128u)) return;  // ablation: workgroup launch cost only
-    const uint32_t tile_l = blockIdx.x / a.nq;  // tile-major: neighbours in dispatch order share the tile
-    const uint32_t q = blockIdx.x % a.nq;
+    const uint32_t tile_l = blockIdx.x / a.qn;  // tile-major: neighbours in dispatch order share the tile
+    const uint32_t q = a.q0 + blockIdx.x % a.qn;
     const uint32_t tile_g = a.tile0 + tile_l;
     const uint64_t doc0 = (uint64_t)tile_g * TILE_DOCS;
     const uint32_t ndocs_tile = (uint32_t)min((uint64_t)TILE_DOCS, a.n_docs - doc0);
@@ -409,6 +549,19 @@ __global__ __launch_bounds__(NT, MIN_WAVES) void score_tiles(const ScoreArgs a) 
     // =============================================================== exact top-k of this tile
     // Thread `tid` owns vec r*NT + tid of the accumulators in round r (conflict-free ds_read_b128); the
     // accumulators are re-read from LDS in every pass instead of being held in registers.
+    if (MODE == 1) {  // term-sharded search: hand the partial sums of this tile to the reduction
+        const uint32_t g = tile_g / a.tpr, t = tile_g % a.tpr;
+        uint4* dst = reinterpret_cast<uint4*>(a.dump + (((uint64_t)g * a.qn + (q - a.q0)) * a.tpr + t) * TILE_DOCS);
+        for (int r = 0; r < rounds; ++r) {
+            uint4 x = a4[r * NT + tid];
+            if (a.dump_add) {
+                const uint4 o = dst[r * NT + tid];
+                x = make_uint4(x.x + o.x, x.y + o.y, x.z + o.z, x.w + o.w);
+            }
+            dst[r * NT + tid] = x;
+        }
+        return;
+    }
     uint64_t* out = a.part + ((uint64_t)tile_l * a.nq + q) * a.k;
     const int k = (int)a.k;
     if (DBG && (a.dbg & 4u)) {  // ablation: no select phase
@@ -416,125 +569,54 @@ __global__ __launch_bounds__(NT, MIN_WAVES) void score_tiles(const ScoreArgs a) 
         return;
     }
 
-    uint32_t mymax = 0;
-    for (int r = 0; r < rounds; ++r) {
-        const uint4 x = a4[r * NT + tid];
-        mymax = max(max(mymax, max(x.x, x.y)), max(x.z, x.w));
-    }
-    // ---- tau0: a lower bound with at least k accumulators at or above it = the k-th largest GROUP maximum.
-    //   k <= 64 : 64 groups of NT/64 consecutive threads (log2(NT/64) shuffle steps), then every wave bisects the
-    //             64 group maxima with ballots (no further barrier);
-    //   k >  64 : groups are single threads (NT maxima, NT/64 per lane of wave 0), one more barrier.
-    constexpr int G = NT / 64;  // threads per group
-    uint32_t gm = mymax;
-#pragma unroll
-    for (int o = 1; o < G; o <<= 1) gm = max(gm, (uint32_t)__shfl_xor(gm, o, 64));
-    if ((lane & (G - 1)) == 0) wmax[tid / G] = gm;
-    if (k > 64) tmax[tid] = mymax;
-    __syncthreads();
-
-    uint32_t tau0 = 1, smax;
-    {
-        const uint32_t v = wmax[lane];  // 64 group maxima, one per lane, in every wave
-        smax = wave_max_u32(v);
-        if (smax == 0) {  // nothing matched in this tile
-            for (int i = tid; i < k; i += NT) out[i] = 0;
-            return;
-        }
-        if (k <= 64) {
-            uint32_t tau = 0;
-            for (int bit = 31 - __clz(smax); bit >= 0; --bit) {
-                const uint32_t t2 = tau | (1u << bit);
-                if (__popcll(__ballot(v >= t2)) >= k) tau = t2;
-            }
-            tau0 = max(tau, 1u);
-        }
-    }
-    if (k > 64 && k <= NT) {
-        if (wave == 0) {
-            uint32_t mine[NW];
-#pragma unroll
-            for (int i = 0; i < NW; ++i) mine[i] = tmax[i * 64 + lane];
-            uint32_t tau = 0;
-            for (int bit = 31 - __clz(smax); bit >= 0; --bit) {
-                const uint32_t t2 = tau | (1u << bit);
-                uint32_t c = 0;
-#pragma unroll
-                for (int i = 0; i < NW; ++i) c += (uint32_t)__popcll(__ballot(mine[i] >= t2));
-                if (c >= (uint32_t)k) tau = t2;
-            }
-            if (lane == 0) ss.tau0 = max(tau, 1u);
-        }
-        __syncthreads();
-        tau0 = ss.tau0;
-    }
-
-    stamp(4);  // thread / wave maxima, tau0
-    // ---- candidates: accumulators >= tau0 as unique global keys (score << 32 | ~ordinal)
-    if (mymax >= tau0) {
-        for (int r = 0; r < rounds; ++r) {
-            const uint4 x = a4[r * NT + tid];
-            const uint32_t sc4[4] = {x.x, x.y, x.z, x.w};
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
-                if (sc4[e] >= tau0) {
-                    const uint32_t local = 4 * (r * NT + tid) + e;
-                    const uint32_t pos = atomicAdd(&ss.n_cand, 1u);
-                    if (pos < CAND)
-                        cand[pos] = ((uint64_t)sc4[e] << 32) | (uint64_t)(0xFFFFFFFFu - (uint32_t)(doc0 + local));
-                }
-        }
-    }
-    __syncthreads();
-    stamp(5);  // candidate collection
-    uint32_t n_cand = ss.n_cand;
-
-    if (n_cand > CAND) {
-        // ---- fallback: bisection for the k-th largest (score, ordinal) key of the whole tile.
-        // local key = score << 16 | (0xFFFF - local ordinal): unique, so exactly min(k, #positive) survive.
-        __syncthreads();  // everyone has read n_cand
-        if (tid == 0) ss.n_cand = 0;
-        const int top = 16 + (32 - __clz(smax));  // bits in use (<= 48 < 64 counter slots)
-        uint64_t tau = 0;
-        int step = 0;
-        for (int bit = top - 1; bit >= 0; --bit, ++step) {
-            const uint64_t t2 = tau | (1ull << bit);
-            uint32_t c = 0;
-            for (int r = 0; r < rounds; ++r) {
-                const uint4 x = a4[r * NT + tid];
-                const uint32_t sc4[4] = {x.x, x.y, x.z, x.w};
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const uint32_t local = 4 * (r * NT + tid) + e;
-                    const uint64_t key = sc4[e] ? (((uint64_t)sc4[e] << 16) | (0xFFFFu - local)) : 0ull;
-                    c += key >= t2;
-                }
-            }
-            c = wave_sum_u32(c);
-            if (lane == 0 && c) atomicAdd(&ss.cnt[step], c);
-            __syncthreads();
-            if (ss.cnt[step] >= (uint32_t)k) tau = t2;
-        }
-        __syncthreads();
-        for (int r = 0; r < rounds; ++r) {
-            const uint4 x = a4[r * NT + tid];
-            const uint32_t sc4[4] = {x.x, x.y, x.z, x.w};
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const uint32_t local = 4 * (r * NT + tid) + e;
-                const uint64_t key = sc4[e] ? (((uint64_t)sc4[e] << 16) | (0xFFFFu - local)) : 0ull;
-                if (key && key >= tau) {
-                    const uint32_t pos = atomicAdd(&ss.n_cand, 1u);
-                    if (pos < CAND)
-                        cand[pos] = ((uint64_t)sc4[e] << 32) | (uint64_t)(0xFFFFFFFFu - (uint32_t)(doc0 + local));
-                }
-            }
-        }
-        __syncthreads();
-        n_cand = min(ss.n_cand, (uint32_t)CAND);  // == min(k, #positive) <= CAND by construction
-    }
-    rank_and_emit<NT>(cand, (int)n_cand, k, out);
+    tile_select<TILE_DOCS, NT, CAND>(a4, cand, tmax, wmax, ss, rounds, doc0, k, out, stamp);
     stamp(6);  // ranking + output
+}
+
+// ------------------------------------------------------------------------------------------------ kernel 1b
+// Term-sharded search, after the reduce-scatter: rank `rank` holds the SUMMED accumulators of its doc range,
+// src[(qi * tpr + t) * TILE_DOCS + i]; one workgroup per (tile of the range, query) selects the exact tile top-k.
+struct SelectArgs {
+    const uint32_t* src;
+    uint64_t* part;   // [tpr][nq][k]
+    uint64_t n_docs;
+    uint32_t n_tiles; // tiles of the whole index
+    uint32_t tpr;
+    uint32_t rank;
+    uint32_t nq, q0, qn, k;
+};
+
+template <int TILE_DOCS, int NT, int CAND>
+__global__ __launch_bounds__(NT) void select_tiles(const SelectArgs a) {
+    using L = TileLds<TILE_DOCS, NT, CAND>;
+    __shared__ __attribute__((aligned(16))) uint8_t lds[L::kTotal];
+    uint4* const a4 = reinterpret_cast<uint4*>(lds);
+    uint8_t* const un = lds + L::kAcc;
+    uint64_t* const cand = reinterpret_cast<uint64_t*>(un);
+    uint32_t* const tmax = reinterpret_cast<uint32_t*>(un + L::kUnion);
+    uint32_t* const wmax = tmax + NT;
+    SelectScratch& ss = *reinterpret_cast<SelectScratch*>(un + L::kUnion + L::kTmax);
+    const uint32_t tid = threadIdx.x;
+    const uint32_t t = blockIdx.x / a.qn, qi = blockIdx.x % a.qn;
+    const uint32_t tile_g = a.rank * a.tpr + t;
+    uint64_t* out = a.part + ((uint64_t)t * a.nq + a.q0 + qi) * a.k;
+    if (tile_g >= a.n_tiles) {  // padding tile of the last rank
+        for (uint32_t i = tid; i < a.k; i += NT) out[i] = 0;
+        return;
+    }
+    const uint64_t doc0 = (uint64_t)tile_g * TILE_DOCS;
+    const uint32_t ndocs_tile = (uint32_t)min((uint64_t)TILE_DOCS, a.n_docs - doc0);
+    const int rounds = (int)((ndocs_tile + 4 * NT - 1) / (4 * NT));
+    const uint4* src = reinterpret_cast<const uint4*>(a.src + ((uint64_t)qi * a.tpr + t) * TILE_DOCS);
+    for (int r = 0; r < rounds; ++r) a4[r * NT + tid] = src[r * NT + tid];
+    if (tid < 64) ss.cnt[tid] = 0;
+    if (tid == 0) {
+        ss.n_cand = 0;
+        ss.tau0 = 1;
+        ss.smax = 0;
+    }
+    __syncthreads();
+    tile_select<TILE_DOCS, NT, CAND>(a4, cand, tmax, wmax, ss, rounds, doc0, (int)a.k, out, [](int) {});
 }
 
 // ------------------------------------------------------------------------------------------------ kernel 2
@@ -650,31 +732,55 @@ __global__ __launch_bounds__(NT) void merge_lists(const MergeArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------ launch
-static int launch_score(hipStream_t st, uint32_t tile_docs, uint32_t ntiles, const ScoreArgs& a) {
-    const uint64_t blocks = (uint64_t)ntiles * a.nq;
+static int launch_score(hipStream_t st, uint32_t tile_docs, uint32_t ntiles, const ScoreArgs& a, bool dump = false) {
+    const uint64_t blocks = (uint64_t)ntiles * a.qn;
     if (blocks == 0) return MSR_OK;
     if (blocks > 0x7FFFFFFFull) {
         set_error("too many workgroups (%llu tiles x queries); split the batch", (unsigned long long)blocks);
         return MSR_E_RANGE;
     }
     switch (tile_docs) {
-#define MSR_LAUNCH(T, N, UU, W)                                                                               \
-    if (a.dbg)                                                                                                \
-        hipLaunchKernelGGL((score_tiles<T, N, UU, W, 1024, true>), dim3((uint32_t)blocks), dim3(N), 0, st, a);  \
+#define MSR_LAUNCH(T, N, UU, W, WR)                                                                           \
+    if (dump)                                                                                                 \
+        hipLaunchKernelGGL((score_tiles<T, N, UU, WR, 512, false, 1>), dim3((uint32_t)blocks), dim3(N), 0, st, a); \
+    else if (a.dbg)                                                                                           \
+        hipLaunchKernelGGL((score_tiles<T, N, UU, WR, 1024, true>), dim3((uint32_t)blocks), dim3(N), 0, st, a); \
     else if (a.k <= 512)                                                                                      \
         hipLaunchKernelGGL((score_tiles<T, N, UU, W, 512, false>), dim3((uint32_t)blocks), dim3(N), 0, st, a);  \
     else                                                                                                      \
-        hipLaunchKernelGGL((score_tiles<T, N, UU, W, 1024, false>), dim3((uint32_t)blocks), dim3(N), 0, st, a); \
+        hipLaunchKernelGGL((score_tiles<T, N, UU, WR, 1024, false>), dim3((uint32_t)blocks), dim3(N), 0, st, a); \
     break;
+        // <tile, threads, chunk loads per bank, min waves/SIMD of the k <= 512 instance, of the other instances>
         // LDS per workgroup = 4 B x tile + 4-8 KiB candidates + maxima -> workgroups (waves) per CU:
-        case 32768: MSR_LAUNCH(32768, 1024, 8, 4)  // 1 (16)
-        case 16384: MSR_LAUNCH(16384, 512, 8, 4)   // 2 (16)
-        case 12288: MSR_LAUNCH(12288, 512, 4, 6)   // 3 (24) with k <= 512
-        case 8192: MSR_LAUNCH(8192, 512, 4, 8)     // 4 (32) with k <= 512
-        case 4096: MSR_LAUNCH(4096, 256, 4, 8)     // 7 (28)
+        case 32768: MSR_LAUNCH(32768, 1024, 8, 4, 4)  // 1 (16)
+        case 16384: MSR_LAUNCH(16384, 512, 8, 4, 4)   // 2 (16)
+        case 12288: MSR_LAUNCH(12288, 512, 4, 4, 4)   // 2 (16)
+        case 8192: MSR_LAUNCH(8192, 512, 4, 8, 6)     // 4 (32) with k <= 512, 3 (24) above
+        case 4096: MSR_LAUNCH(4096, 256, 4, 6, 5)     // 7 (28)
 #undef MSR_LAUNCH
         default:
             set_error("no kernel instance for tile_docs=%u (supported: 4096, 8192, 12288, 16384, 32768)", tile_docs);
+            return MSR_E_RANGE;
+    }
+    HIP_TRY(hipGetLastError());
+    return MSR_OK;
+}
+
+static int launch_select(hipStream_t st, uint32_t tile_docs, const SelectArgs& a) {
+    const uint64_t blocks = (uint64_t)a.tpr * a.qn;
+    if (blocks == 0) return MSR_OK;
+    if (blocks > 0x7FFFFFFFull) {
+        set_error("too many workgroups in select_tiles");
+        return MSR_E_RANGE;
+    }
+    switch (tile_docs) {
+        case 32768: hipLaunchKernelGGL((select_tiles<32768, 1024, 1024>), dim3((uint32_t)blocks), dim3(1024), 0, st, a); break;
+        case 16384: hipLaunchKernelGGL((select_tiles<16384, 512, 1024>), dim3((uint32_t)blocks), dim3(512), 0, st, a); break;
+        case 12288: hipLaunchKernelGGL((select_tiles<12288, 512, 1024>), dim3((uint32_t)blocks), dim3(512), 0, st, a); break;
+        case 8192: hipLaunchKernelGGL((select_tiles<8192, 512, 1024>), dim3((uint32_t)blocks), dim3(512), 0, st, a); break;
+        case 4096: hipLaunchKernelGGL((select_tiles<4096, 256, 1024>), dim3((uint32_t)blocks), dim3(256), 0, st, a); break;
+        default:
+            set_error("no kernel instance for tile_docs=%u", tile_docs);
             return MSR_E_RANGE;
     }
     HIP_TRY(hipGetLastError());
@@ -837,6 +943,12 @@ struct msr_batch {
     float* d_sf32 = nullptr;
     int32_t* d_n = nullptr;
     unsigned long long* d_stamps = nullptr;  // diagnostic (MSR_DEBUG_FLAGS bit 3)
+    // term-sharded search
+    uint32_t* d_S = nullptr;      // [G][Qt][tpr*tile] partial accumulators of one query tile (reduce-scatter send buffer)
+    uint32_t* d_R = nullptr;      // [Qt][tpr*tile] summed accumulators of this rank's doc range
+    uint64_t* d_tpart = nullptr;  // [tpr][nq][kmax] per-tile keys of this rank's doc range
+    size_t S_elems = 0, R_elems = 0, tpart_elems = 0;
+    int term_shard = -1, term_nshards = 0;  // >= 0: the batch holds only the query terms of that term range
     hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr;  // the current call's events (borrowed from `events`)
     std::vector<hipEvent_t> events;  // 3 per recorded search call since the last timing reset
     size_t calls = 0;                // recorded calls
@@ -847,7 +959,7 @@ static void batch_free(msr_batch* b) {
     if (!b) return;
     if (b->ix && b->ix->dev) (void)hipSetDevice(b->ix->dev->device);
     void* ptrs[] = {b->d_qptr, b->d_qterm, b->d_qw, b->d_qdense, b->d_part, b->d_keys, b->d_gather, b->d_ord, b->d_su32, b->d_sf32, b->d_n,
-                    b->d_stamps};
+                    b->d_stamps, b->d_S, b->d_R, b->d_tpart};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     for (hipEvent_t e : b->events)
@@ -857,8 +969,26 @@ static void batch_free(msr_batch* b) {
 
 extern "C" {
 
-int msr_batch_create(msr_index* ix, const int64_t* q_ptr, const int32_t* q_term, const int32_t* q_w, int nq, int kmax,
-                     uint32_t flags, msr_batch** out) {
+}  // extern "C"
+
+// Term ownership for term-range sharding: G contiguous term-id ranges balanced by postings (cumulative df), the
+// same on every rank because it depends only on the index. bounds has G+1 entries.
+static void term_bounds(const msr::HostIndex& hx, int G, std::vector<uint32_t>& bounds) {
+    const uint32_t V = hx.h->n_terms;
+    uint64_t total = 0;
+    for (uint32_t v = 0; v < V; ++v) total += hx.df[v];
+    bounds.assign((size_t)G + 1, V);
+    bounds[0] = 0;
+    uint64_t acc = 0;
+    int g = 1;
+    for (uint32_t v = 0; v < V && g < G; ++v) {
+        acc += hx.df[v];
+        while (g < G && acc * (uint64_t)G >= total * (uint64_t)g) bounds[g++] = v + 1;
+    }
+}
+
+static int batch_create_impl(msr_index* ix, const int64_t* q_ptr, const int32_t* q_term, const int32_t* q_w, int nq,
+                             int kmax, uint32_t flags, int shard, int n_shards, msr_batch** out) {
     if (!out) {
         set_error("msr_batch_create: null output");
         return MSR_E_INVAL;
@@ -879,6 +1009,17 @@ int msr_batch_create(msr_index* ix, const int64_t* q_ptr, const int32_t* q_term,
     const IndexHeader* h = ix->host.h;
     DeviceIndex* d = ix->dev;
     compute_df_shard(ix);
+    uint32_t term_lo = 0, term_hi = h->n_terms;
+    if (n_shards > 0) {
+        if (shard < 0 || shard >= n_shards) {
+            set_error("bad term shard %d of %d", shard, n_shards);
+            return MSR_E_INVAL;
+        }
+        std::vector<uint32_t> tb;
+        term_bounds(ix->host, n_shards, tb);
+        term_lo = tb[shard];
+        term_hi = tb[shard + 1];
+    }
 
     // ---- host-side query normalisation (what pyserini does before handing the query to Lucene):
     // OOV (term < 0) and non-positive weights vanish, terms present in every doc are dropped when asked,
@@ -917,7 +1058,8 @@ int msr_batch_create(msr_index* ix, const int64_t* q_ptr, const int32_t* q_term,
             }
             if ((flags & MSR_F_DROP_DF_EQ_N) && ix->host.df[t] == h->n_docs) continue;
             if (ix->host.df[t] == 0) continue;
-            bound += (uint64_t)w * ix->host.maxw[t];
+            bound += (uint64_t)w * ix->host.maxw[t];  // the bound covers the WHOLE query, whoever owns the term
+            if ((uint32_t)t < term_lo || (uint32_t)t >= term_hi) continue;
             sum_df += d->df_shard[t];
             ++n_kept;
             const int ds = ix->host.dense_slot[t];
@@ -954,6 +1096,8 @@ int msr_batch_create(msr_index* ix, const int64_t* q_ptr, const int32_t* q_term,
     b->nq = nq;
     b->kmax = kmax;
     b->nnz = n_kept;
+    b->term_shard = n_shards > 0 ? shard : -1;
+    b->term_nshards = n_shards > 0 ? n_shards : 0;
     b->sum_df = sum_df;
     auto fail = [&](int rc) {
         batch_free(b);
@@ -989,6 +1133,22 @@ int msr_batch_create(msr_index* ix, const int64_t* q_ptr, const int32_t* q_term,
     return MSR_OK;
 }
 
+extern "C" {
+
+int msr_batch_create(msr_index* ix, const int64_t* q_ptr, const int32_t* q_term, const int32_t* q_w, int nq, int kmax,
+                     uint32_t flags, msr_batch** out) {
+    return batch_create_impl(ix, q_ptr, q_term, q_w, nq, kmax, flags, 0, 0, out);
+}
+
+int msr_batch_create_termshard(msr_index* ix, const int64_t* q_ptr, const int32_t* q_term, const int32_t* q_w, int nq,
+                               int kmax, uint32_t flags, int shard, int n_shards, msr_batch** out) {
+    if (n_shards < 1) {
+        set_error("msr_batch_create_termshard: n_shards must be >= 1");
+        return MSR_E_INVAL;
+    }
+    return batch_create_impl(ix, q_ptr, q_term, q_w, nq, kmax, flags, shard, n_shards, out);
+}
+
 static int batch_search_local(msr_batch* b, int k, bool final_arrays) {
     msr_index* ix = b->ix;
     DeviceIndex* d = ix->dev;
@@ -1021,7 +1181,12 @@ static int batch_search_local(msr_batch* b, int k, bool final_arrays) {
     sa.n_terms = h->n_terms;
     sa.tile0 = ix->shard_tile0;
     sa.nq = (uint32_t)b->nq;
+    sa.q0 = 0;
+    sa.qn = (uint32_t)b->nq;
     sa.k = (uint32_t)k;
+    sa.dump = nullptr;
+    sa.tpr = 1;
+    sa.dump_add = 0;
     {
         const char* dbg = getenv("MSR_DEBUG_FLAGS");
         sa.dbg = dbg ? (uint32_t)strtoul(dbg, nullptr, 0) : 0u;
@@ -1316,21 +1481,9 @@ int msr_comm_destroy(msr_index* ix) {
     return MSR_OK;
 }
 
-int msr_batch_search_sharded(msr_batch* b, int k) {
-    if (!b) {
-        set_error("msr_batch_search_sharded: null batch");
-        return MSR_E_INVAL;
-    }
-    if (k < 1 || k > b->kmax) {
-        set_error("k=%d outside [1, kmax=%d]", k, b->kmax);
-        return MSR_E_RANGE;
-    }
+// all-gather of every rank's [nq][k] keys (d_keys) + exact merge of the n_ranks lists into the result arrays
+static int exchange_and_merge(msr_batch* b, int k) {
     DeviceIndex* d = b->ix->dev;
-    if (!d->comm) {
-        set_error("msr_batch_search_sharded: call msr_comm_init first");
-        return MSR_E_COMM;
-    }
-    HIP_TRY(hipSetDevice(d->device));
     const size_t per = std::max<size_t>((size_t)b->nq * b->kmax, 1);
     if (!b->d_gather) {
         if (hipMalloc(&b->d_gather, per * 8 * d->n_ranks) != hipSuccess) {
@@ -1338,8 +1491,6 @@ int msr_batch_search_sharded(msr_batch* b, int k) {
             return MSR_E_NOMEM;
         }
     }
-    int rc = batch_search_local(b, k, false);  // per-shard exact top-k keys in d_keys ([nq][k])
-    if (rc != MSR_OK) return rc;
     const size_t cnt = (size_t)b->nq * k;
     if (cnt) {
         ncclResult_t r = ncclAllGather(b->d_keys, b->d_gather, cnt, ncclUint64, d->comm, d->stream);
@@ -1359,10 +1510,313 @@ int msr_batch_search_sharded(msr_batch* b, int k) {
     ma.out_score_u32 = b->d_su32;
     ma.out_score = b->d_sf32;
     ma.out_n = b->d_n;
-    rc = launch_merge(d->stream, ma);
+    int rc = launch_merge(d->stream, ma);
     if (rc != MSR_OK) return rc;
     HIP_TRY(hipEventRecord(b->ev2, d->stream));
     return MSR_OK;
+}
+
+static int check_sharded_call(msr_batch* b, int k, const char* who) {
+    if (!b) {
+        set_error("%s: null batch", who);
+        return MSR_E_INVAL;
+    }
+    if (k < 1 || k > b->kmax) {
+        set_error("k=%d outside [1, kmax=%d]", k, b->kmax);
+        return MSR_E_RANGE;
+    }
+    if (!b->ix->dev->comm) {
+        set_error("%s: call msr_comm_init first", who);
+        return MSR_E_COMM;
+    }
+    return MSR_OK;
+}
+
+int msr_batch_search_sharded(msr_batch* b, int k) {
+    int rc = check_sharded_call(b, k, "msr_batch_search_sharded");
+    if (rc != MSR_OK) return rc;
+    HIP_TRY(hipSetDevice(b->ix->dev->device));
+    rc = batch_search_local(b, k, false);  // per-shard exact top-k keys in d_keys ([nq][k])
+    if (rc != MSR_OK) return rc;
+    return exchange_and_merge(b, k);
+}
+
+// ------------------------------------------------------------------------------------------------ term-range shards
+// Partial sums are not mergeable by top-k alone, so the exact protocol moves the accumulators:
+//   every rank scores its OWN TERM RANGE of every query against ALL docs and dumps the accumulator tiles,
+//   ncclReduceScatter(sum) hands rank r the complete sums of doc range r, rank r selects its range's exact top-k,
+//   and the per-range lists are all-gathered and merged as for doc-range shards.
+struct TermShardPlan {
+    uint32_t G, tpr, tile;
+    uint64_t range_elems;  // tpr * tile accumulators per query and doc range
+    uint32_t qt;           // queries per pass
+};
+
+static TermShardPlan term_plan(const msr_index* ix, int G, int nq) {
+    TermShardPlan p;
+    const IndexHeader* h = ix->host.h;
+    p.G = (uint32_t)G;
+    p.tile = h->tile_docs;
+    p.tpr = (h->n_tiles + G - 1) / G;
+    p.range_elems = (uint64_t)p.tpr * p.tile;
+    const uint64_t per_query = p.range_elems * G * 4;                     // bytes of S per query
+    const uint64_t budget = 4ull << 30;                                     // 4 GiB send buffer
+    p.qt = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)std::max(nq, 1), budget / std::max<uint64_t>(per_query, 1)));
+    return p;
+}
+
+static int ensure_buf(void** p, size_t* have, size_t want_elems, size_t elem_bytes, const char* what) {
+    if (*p && *have >= want_elems) return MSR_OK;
+    if (*p) (void)hipFree(*p);
+    *p = nullptr;
+    if (hipMalloc(p, std::max<size_t>(want_elems, 1) * elem_bytes) != hipSuccess) {
+        set_error("hipMalloc of %zu bytes for %s failed", want_elems * elem_bytes, what);
+        *have = 0;
+        return MSR_E_NOMEM;
+    }
+    *have = want_elems;
+    return MSR_OK;
+}
+
+static void fill_score_args(ScoreArgs& sa, msr_batch* b, int k) {
+    msr_index* ix = b->ix;
+    DeviceIndex* d = ix->dev;
+    sa.seg_ptr = d->d_seg_ptr;
+    sa.postings = d->d_postings;
+    sa.q_ptr = b->d_qptr;
+    sa.q_term = b->d_qterm;
+    sa.q_w = b->d_qw;
+    sa.dense = d->d_dense;
+    sa.q_dense = b->d_qdense;
+    sa.n_pairs = d->n_pairs;
+    sa.part = b->d_part;
+    sa.n_docs = ix->host.h->n_docs;
+    sa.vec_base = d->vec_base;
+    sa.n_terms = ix->host.h->n_terms;
+    sa.tile0 = ix->shard_tile0;
+    sa.nq = (uint32_t)b->nq;
+    sa.q0 = 0;
+    sa.qn = (uint32_t)b->nq;
+    sa.k = (uint32_t)k;
+    sa.dump = nullptr;
+    sa.tpr = 1;
+    sa.dump_add = 0;
+    sa.dbg = 0;
+    sa.stamps = nullptr;
+}
+
+int msr_batch_search_termshard(msr_batch* b, int k) {
+    int rc = check_sharded_call(b, k, "msr_batch_search_termshard");
+    if (rc != MSR_OK) return rc;
+    msr_index* ix = b->ix;
+    DeviceIndex* d = ix->dev;
+    const IndexHeader* h = ix->host.h;
+    if (ix->shard_ntiles != h->n_tiles) {
+        set_error("term-sharded search needs a handle that holds every doc tile (open it with msr_index_open)");
+        return MSR_E_INVAL;
+    }
+    if (b->term_nshards != d->n_ranks || b->term_shard != d->rank) {
+        set_error("the batch was created for term shard %d/%d but the communicator is rank %d/%d", b->term_shard,
+                  b->term_nshards, d->rank, d->n_ranks);
+        return MSR_E_INVAL;
+    }
+    HIP_TRY(hipSetDevice(d->device));
+    const TermShardPlan p = term_plan(ix, d->n_ranks, b->nq);
+    rc = ensure_buf((void**)&b->d_S, &b->S_elems, (size_t)p.qt * p.range_elems * p.G, 4, "the reduce-scatter send buffer");
+    if (rc == MSR_OK && p.G > 1)
+        rc = ensure_buf((void**)&b->d_R, &b->R_elems, (size_t)p.qt * p.range_elems, 4, "the reduce-scatter receive buffer");
+    if (rc == MSR_OK)
+        rc = ensure_buf((void**)&b->d_tpart, &b->tpart_elems, (size_t)p.tpr * b->nq * b->kmax, 8, "the per-tile keys");
+    if (rc != MSR_OK) return rc;
+    if (b->calls >= 4096) b->calls = 0;
+    while (b->events.size() < (b->calls + 1) * 3) {
+        hipEvent_t e = nullptr;
+        HIP_TRY(hipEventCreate(&e));
+        b->events.push_back(e);
+    }
+    b->ev0 = b->events[b->calls * 3 + 0];
+    b->ev1 = b->events[b->calls * 3 + 1];
+    b->ev2 = b->events[b->calls * 3 + 2];
+    b->calls++;
+    HIP_TRY(hipEventRecord(b->ev0, d->stream));
+    for (uint32_t q0 = 0; q0 < (uint32_t)b->nq; q0 += p.qt) {
+        const uint32_t qn = std::min<uint32_t>(p.qt, (uint32_t)b->nq - q0);
+        const size_t send = (size_t)qn * p.range_elems * p.G;
+        HIP_TRY(hipMemsetAsync(b->d_S, 0, send * 4, d->stream));
+        ScoreArgs sa;
+        fill_score_args(sa, b, k);
+        sa.q0 = q0;
+        sa.qn = qn;
+        sa.dump = b->d_S;
+        sa.tpr = p.tpr;
+        rc = launch_score(d->stream, h->tile_docs, h->n_tiles, sa, true);
+        if (rc != MSR_OK) return rc;
+        const uint32_t* reduced = b->d_S;
+        if (p.G > 1) {
+            ncclResult_t r = ncclReduceScatter(b->d_S, b->d_R, (size_t)qn * p.range_elems, ncclUint32, ncclSum, d->comm, d->stream);
+            if (r != ncclSuccess) {
+                set_error("ncclReduceScatter failed: %s", ncclGetErrorString(r));
+                return MSR_E_COMM;
+            }
+            reduced = b->d_R;
+        }
+        SelectArgs se;
+        se.src = reduced;
+        se.part = b->d_tpart;
+        se.n_docs = h->n_docs;
+        se.n_tiles = h->n_tiles;
+        se.tpr = p.tpr;
+        se.rank = (uint32_t)d->rank;
+        se.nq = (uint32_t)b->nq;
+        se.q0 = q0;
+        se.qn = qn;
+        se.k = (uint32_t)k;
+        rc = launch_select(d->stream, h->tile_docs, se);
+        if (rc != MSR_OK) return rc;
+    }
+    HIP_TRY(hipEventRecord(b->ev1, d->stream));
+    MergeArgs ma;
+    ma.lists = b->d_tpart;
+    ma.list_stride = (uint64_t)b->nq * k;
+    ma.n_lists = p.tpr;
+    ma.nq = (uint32_t)b->nq;
+    ma.k = (uint32_t)k;
+    ma.out_keys = b->d_keys;
+    ma.out_ord = nullptr;
+    ma.out_score_u32 = b->d_su32;
+    ma.out_score = b->d_sf32;
+    ma.out_n = b->d_n;
+    rc = launch_merge(d->stream, ma);
+    if (rc != MSR_OK) return rc;
+    b->last_k = k;
+    b->timed = true;
+    return exchange_and_merge(b, k);
+}
+
+// The same protocol played on ONE GPU for `n_shards` logical term shards (tests, and a cross-check of the partition):
+// the shards' dumps are summed in place (dump_add) instead of by ncclReduceScatter; every logical rank then selects
+// its doc range and the n_shards lists are merged.
+int msr_search_termshard_emulated(msr_index* ix, const int64_t* q_ptr, const int32_t* q_term, const int32_t* q_w, int nq,
+                                  int k, uint32_t flags, int n_shards, uint32_t* out_doc_ord, float* out_score,
+                                  uint32_t* out_score_u32, int32_t* out_n) {
+    if (!ix || n_shards < 1 || n_shards > 64) {
+        set_error("msr_search_termshard_emulated: bad argument");
+        return MSR_E_INVAL;
+    }
+    if (!ix->dev) {
+        set_error("index handle has no HIP device bound; there is no CPU scoring path");
+        return MSR_E_NODEVICE;
+    }
+    if (ix->shard_ntiles != ix->host.h->n_tiles) {
+        set_error("term-sharded search needs a handle that holds every doc tile");
+        return MSR_E_INVAL;
+    }
+    DeviceIndex* d = ix->dev;
+    const IndexHeader* h = ix->host.h;
+    std::vector<msr_batch*> bs((size_t)n_shards, nullptr);
+    uint32_t* d_S = nullptr;
+    uint64_t *d_tpart = nullptr, *d_lists = nullptr;
+    int rc = MSR_OK;
+    auto cleanup = [&]() {
+        for (msr_batch* x : bs) batch_free(x);
+        if (d_S) (void)hipFree(d_S);
+        if (d_tpart) (void)hipFree(d_tpart);
+        if (d_lists) (void)hipFree(d_lists);
+    };
+    for (int g = 0; g < n_shards && rc == MSR_OK; ++g)
+        rc = batch_create_impl(ix, q_ptr, q_term, q_w, nq, k, flags, g, n_shards, &bs[g]);
+    if (rc != MSR_OK) {
+        cleanup();
+        return rc;
+    }
+    const TermShardPlan p = term_plan(ix, n_shards, nq);
+    const size_t per = std::max<size_t>((size_t)nq * k, 1);
+    if (hipSetDevice(d->device) != hipSuccess ||
+        hipMalloc(&d_S, std::max<size_t>((size_t)p.qt * p.range_elems * p.G, 1) * 4) != hipSuccess ||
+        hipMalloc(&d_tpart, std::max<size_t>((size_t)p.tpr * per, 1) * 8) != hipSuccess ||
+        hipMalloc(&d_lists, per * 8 * n_shards) != hipSuccess) {
+        set_error("hipMalloc failed in msr_search_termshard_emulated");
+        cleanup();
+        return MSR_E_NOMEM;
+    }
+    // pass 1..: accumulators of every query tile, summed over the logical term shards; selection per logical rank
+    // writes into that rank's slice of d_lists after a per-rank merge of its tpr tile lists.
+    std::vector<uint64_t*> rank_part((size_t)n_shards, nullptr);
+    for (int r = 0; r < n_shards && rc == MSR_OK; ++r)
+        if (hipMalloc(&rank_part[r], std::max<size_t>((size_t)p.tpr * per, 1) * 8) != hipSuccess) {
+            set_error("hipMalloc failed in msr_search_termshard_emulated");
+            rc = MSR_E_NOMEM;
+        }
+    for (uint32_t q0 = 0; q0 < (uint32_t)nq && rc == MSR_OK; q0 += p.qt) {
+        const uint32_t qn = std::min<uint32_t>(p.qt, (uint32_t)nq - q0);
+        if (hipMemsetAsync(d_S, 0, (size_t)qn * p.range_elems * p.G * 4, d->stream) != hipSuccess) {
+            set_error("hipMemsetAsync failed");
+            rc = MSR_E_HIP;
+            break;
+        }
+        for (int g = 0; g < n_shards && rc == MSR_OK; ++g) {
+            ScoreArgs sa;
+            fill_score_args(sa, bs[g], k);
+            sa.q0 = q0;
+            sa.qn = qn;
+            sa.dump = d_S;
+            sa.tpr = p.tpr;
+            sa.dump_add = 1;
+            rc = launch_score(d->stream, h->tile_docs, h->n_tiles, sa, true);
+        }
+        for (int r = 0; r < n_shards && rc == MSR_OK; ++r) {
+            SelectArgs se;
+            se.src = d_S + (size_t)r * qn * p.range_elems;
+            se.part = rank_part[r];
+            se.n_docs = h->n_docs;
+            se.n_tiles = h->n_tiles;
+            se.tpr = p.tpr;
+            se.rank = (uint32_t)r;
+            se.nq = (uint32_t)nq;
+            se.q0 = q0;
+            se.qn = qn;
+            se.k = (uint32_t)k;
+            rc = launch_select(d->stream, h->tile_docs, se);
+        }
+    }
+    for (int r = 0; r < n_shards && rc == MSR_OK; ++r) {
+        MergeArgs ma;
+        ma.lists = rank_part[r];
+        ma.list_stride = (uint64_t)nq * k;
+        ma.n_lists = p.tpr;
+        ma.nq = (uint32_t)nq;
+        ma.k = (uint32_t)k;
+        ma.out_keys = d_lists + (size_t)r * nq * k;
+        ma.out_ord = nullptr;
+        ma.out_score_u32 = nullptr;
+        ma.out_score = nullptr;
+        ma.out_n = nullptr;
+        rc = launch_merge(d->stream, ma);
+    }
+    if (rc == MSR_OK) {
+        msr_batch* b0 = bs[0];
+        MergeArgs ma;
+        ma.lists = d_lists;
+        ma.list_stride = (uint64_t)nq * k;
+        ma.n_lists = (uint32_t)n_shards;
+        ma.nq = (uint32_t)nq;
+        ma.k = (uint32_t)k;
+        ma.out_keys = nullptr;
+        ma.out_ord = b0->d_ord;
+        ma.out_score_u32 = b0->d_su32;
+        ma.out_score = b0->d_sf32;
+        ma.out_n = b0->d_n;
+        rc = launch_merge(d->stream, ma);
+        if (rc == MSR_OK) {
+            b0->last_k = k;
+            rc = msr_batch_fetch(b0, out_doc_ord, out_score, out_score_u32, out_n);
+        }
+    }
+    (void)hipStreamSynchronize(d->stream);
+    for (uint64_t* x : rank_part)
+        if (x) (void)hipFree(x);
+    cleanup();
+    return rc;
 }
 
 }  // extern "C"

@@ -169,8 +169,21 @@ class SparseIndex:
                                    ptr(su), ptr(n)))
         return ords, sc, su, n
 
-    def batch(self, q_ptr, q_term, q_w, kmax, drop_df_eq_n=True):
-        return QueryBatch(self, q_ptr, q_term, q_w, kmax, drop_df_eq_n)
+    def batch(self, q_ptr, q_term, q_w, kmax, drop_df_eq_n=True, term_shard=None):
+        return QueryBatch(self, q_ptr, q_term, q_w, kmax, drop_df_eq_n, term_shard)
+
+    def search_termshard_emulated(self, q_ptr, q_term, q_w, k, n_shards, drop_df_eq_n=True):
+        """Term-range sharded search protocol for `n_shards` logical shards on this one GPU."""
+        q_ptr, q_term, q_w = _cabi.as_csr(q_ptr, q_term, q_w)
+        nq = len(q_ptr) - 1
+        ords = np.empty((nq, k), dtype=np.uint32)
+        sc = np.empty((nq, k), dtype=np.float32)
+        su = np.empty((nq, k), dtype=np.uint32)
+        n = np.zeros(nq, dtype=np.int32)
+        flags = MSR_F_DROP_DF_EQ_N if drop_df_eq_n else 0
+        check(lib().msr_search_termshard_emulated(self._h, ptr(q_ptr), ptr(q_term), ptr(q_w), nq, int(k), flags,
+                                                  int(n_shards), ptr(ords), ptr(sc), ptr(su), ptr(n)))
+        return ords, sc, su, n
 
     def merge_lists(self, ords, scores_u32, n, k):
         """Exact top-k merge (same tie rule) of `L` per-shard lists: ords/scores [L,nq,k], n [L,nq]."""
@@ -204,20 +217,27 @@ def comm_unique_id():
 class QueryBatch:
     """Queries uploaded once; searches run on the index's HIP stream with inputs and outputs resident in HBM."""
 
-    def __init__(self, index, q_ptr, q_term, q_w, kmax, drop_df_eq_n=True):
+    def __init__(self, index, q_ptr, q_term, q_w, kmax, drop_df_eq_n=True, term_shard=None):
         q_ptr, q_term, q_w = _cabi.as_csr(q_ptr, q_term, q_w)
         self.index = index
         self.nq = len(q_ptr) - 1
         self.kmax = int(kmax)
         self._h = C.c_void_p()
         flags = MSR_F_DROP_DF_EQ_N if drop_df_eq_n else 0
-        check(lib().msr_batch_create(index._h, ptr(q_ptr), ptr(q_term), ptr(q_w), self.nq, self.kmax, flags,
-                                     C.byref(self._h)))
+        if term_shard is None:
+            check(lib().msr_batch_create(index._h, ptr(q_ptr), ptr(q_term), ptr(q_w), self.nq, self.kmax, flags,
+                                         C.byref(self._h)))
+        else:  # (shard, n_shards): keep only the query terms of that term range
+            check(lib().msr_batch_create_termshard(index._h, ptr(q_ptr), ptr(q_term), ptr(q_w), self.nq, self.kmax,
+                                                   flags, int(term_shard[0]), int(term_shard[1]), C.byref(self._h)))
         self._k = 0
 
     def search(self, k, sharded=False):
-        """Enqueue one search (asynchronous). sharded=True adds the RCCL all-gather + global merge."""
-        if sharded:
+        """Enqueue one search (asynchronous). sharded=True adds the RCCL all-gather + global merge (doc-range shards);
+        sharded="terms" runs the term-range protocol (reduce-scatter of accumulators, then the same tail)."""
+        if sharded == "terms":
+            check(lib().msr_batch_search_termshard(self._h, int(k)))
+        elif sharded:
             check(lib().msr_batch_search_sharded(self._h, int(k)))
         else:
             check(lib().msr_batch_search(self._h, int(k)))

@@ -273,3 +273,39 @@ def test_merge_of_many_tile_lists(m, tmp_path):
     # 37 tiles x k=100 = 3 700 partial keys per query: more than the merge kernel's LDS buffer, so the list-head
     # threshold path (and, with k = 1000 > #lists, the full bisection) is exercised
     _case(m, tmp_path, 150000, 16, 120, 30, 2000, seed=77, tile_docs=4096, ks=[10, 100, 1000])
+
+
+@pytest.mark.parametrize("tile_docs", [4096, 8192])
+def test_term_range_shards_emulated(m, tmp_path, tile_docs):
+    # the term-sharded protocol (dump accumulators -> sum -> select per doc range -> merge) for G logical shards on
+    # one GPU must reproduce the unsharded answer exactly; 30 000 docs = 8 / 4 tiles, not divisible by every G
+    docs, (qp, qt, qw) = helpers.synth(30000, 48, 150, 40, 3000, seed=91)
+    path = m.build_index_from_csr(str(tmp_path / "t.idx"), *docs, 3000, tile_docs=tile_docs)
+    oix, _ = helpers.taat_oracle(docs, 3000)
+    with m.SparseIndex(path, device=0) as ix:
+        for k in (10, 100):
+            want = oix.search(qp, qt, qw, k, threads=8)
+            for g in (1, 2, 3, 8):
+                helpers.assert_same_results(ix.search_termshard_emulated(qp, qt, qw, k, g), want, k)
+        # a doc-range shard handle cannot run the term protocol
+        with m.SparseIndex(path, device=0, shard=0, n_shards=2) as sh:
+            with pytest.raises(Exception, match="every doc tile"):
+                sh.search_termshard_emulated(qp, qt, qw, 10, 2)
+
+
+def test_term_range_shards_rccl_single_rank(m, tmp_path):
+    docs, (qp, qt, qw) = helpers.synth(20000, 32, 80, 30, 3000, seed=93)
+    path = m.build_index_from_csr(str(tmp_path / "t1.idx"), *docs, 3000, tile_docs=4096)
+    oix, _ = helpers.taat_oracle(docs, 3000)
+    with m.SparseIndex(path, device=0) as ix:
+        ix.comm_init(1, 0, m.comm_unique_id())
+        b = ix.batch(qp, qt, qw, 10, term_shard=(0, 1))
+        b.search(10, sharded="terms")
+        helpers.assert_same_results(b.fetch(), oix.search(qp, qt, qw, 10), 10)
+        b.close()
+        # a batch made for another partition is refused
+        b2 = ix.batch(qp, qt, qw, 10, term_shard=(1, 2))
+        with pytest.raises(Exception, match="term shard"):
+            b2.search(10, sharded="terms")
+        b2.close()
+        ix.comm_destroy()
