@@ -44,6 +44,14 @@ class Ranks:
         self.world = int(os.environ.get("WORLD_SIZE", "1"))
         self.rank = int(os.environ.get("RANK", "0"))
         self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        try:  # rehearsals with more ranks than GPUs (1-GPU box) wrap around; a real node has one GPU per rank
+            import torch
+
+            n_dev = torch.cuda.device_count()
+            if n_dev > 0:
+                self.local_rank %= n_dev
+        except Exception:
+            pass
         self.dist = None
         if self.world > 1:
             import datetime
@@ -293,10 +301,36 @@ def run_c4(args, ranks, m, wlmod):
                 out["cpu_baseline"] = cb
                 out["parity"] = par
                 out["speedup_vs_cpu"] = round(out["value"] / cb["value"], 1)
+        doc_sharded_result = batch.fetch() if sharded else None
         batch.close()
         if sharded:
             ix.comm_destroy()
         ix.close()
+        if sharded and not args.no_term_shards:
+            # the north star's literal partition: term-range shards. Exact, but the exchange is a reduce-scatter of
+            # u32 accumulators (nq x N x 4 B), so it is exchange-bound by construction.
+            terr = None
+            try:
+                ixf = m.SparseIndex(path, device=ranks.local_rank)              # every doc tile, own term range
+                uid = ranks.bcast_bytes(m.comm_unique_id() if ranks.rank == 0 else None, 128)
+                ixf.comm_init(ranks.world, ranks.rank, uid)
+                tb = ixf.batch(qp, qt, qw, 10, term_shard=(ranks.rank, ranks.world))
+            except Exception as e:
+                terr = e
+            if ranks.any_failed(terr is not None):
+                out["term_range_shards"] = {"error": f"setup failed on some rank (this rank: {terr})"}
+            else:
+                twall, _, _ = timed_steps(tb, 10, max(1, min(args.steps, 3)), 1, ranks, sharded="terms")
+                tsteps = max(1, min(args.steps, 3))
+                tres = tb.fetch()
+                same = all((x == y).all() for x, y in zip(tres, doc_sharded_result))
+                out["term_range_shards"] = {
+                    "value": round(nq * tsteps / twall, 1), "unit": "queries/s", "ms_per_step": round(twall / tsteps * 1e3, 2),
+                    "steps": tsteps, "identical_to_doc_range_result": bool(same),
+                    "exchange": "ncclReduceScatter(sum) of u32 accumulator tiles, then ncclAllGather of per-range top-k"}
+                tb.close()
+                ixf.comm_destroy()
+                ixf.close()
     finally:
         ranks.barrier()
         if ranks.rank == 0:
@@ -308,6 +342,10 @@ def run_c4(args, ranks, m, wlmod):
 
 
 def main():
+    # stdout carries exactly ONE JSON line: keep a private handle to it and point fd 1 at stderr, so that banners
+    # printed by native libraries (RCCL prints its version block at communicator init) cannot pollute it
+    real_stdout = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -320,6 +358,7 @@ def main():
     ap.add_argument("--dense-max", type=int, default=-1, help="index build option dense_max_terms (-1: library default)")
     ap.add_argument("--dense-density", type=float, default=-1.0, help="index build option dense_min_density")
     ap.add_argument("--no-c4", action="store_true", help="skip the 1 M-doc extra object")
+    ap.add_argument("--no-term-shards", action="store_true", help="skip the term-range sharded variant at N > 1")
     ap.add_argument("--only-c4", action="store_true", help="(profiling) run only the 1 M-doc workload")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline / parity sample")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
@@ -347,7 +386,7 @@ def main():
             log(f"[bench r{ranks.rank}] c4_1m failed: {c4['error']}")
         out["c4_1m"] = c4
     if ranks.rank == 0:
-        print(json.dumps(out), flush=True)
+        print(json.dumps(out), file=real_stdout, flush=True)
     ranks.close()
 
 
