@@ -160,6 +160,17 @@ int msr_merge_lists(msr_index* ix, int n_lists, int nq, int k, const uint32_t* d
                     const int32_t* n, uint32_t* out_doc_ord, float* out_score, uint32_t* out_score_u32,
                     int32_t* out_n);
 
+/* ---- dense flat inner-product search (hybrid path): replaces tevatron FaissFlatSearcher / faiss IndexFlatIP with
+ * fp16 storage (src/search.py:232-237,254-270; call site search_queries src/search.py:55-63).
+ * p_fp16 / q_fp16 are row-major IEEE fp16 matrices ([n][h] / [nq][h], h a multiple of 16); scores are f32-accumulated
+ * on MFMA. Outputs [nq][k]: row indices (0xFFFFFFFF padding), order-preserving u32 keys of the f32 scores
+ * (key = bits ^ 0x80000000 for non-negative, ~bits for negative floats; 0 = padding) and the hit count. */
+typedef struct msr_dense msr_dense;
+int msr_dense_open(const uint16_t* p_fp16, uint64_t n, uint32_t h, int device, msr_dense** out);
+int msr_dense_search(msr_dense* dx, const uint16_t* q_fp16, int nq, int k, uint32_t* out_idx, uint32_t* out_key,
+                     int32_t* out_n, float* gemm_ms, float* select_ms);
+void msr_dense_close(msr_dense* dx);
+
 /* ---- synthetic encode step (SURVEY.md §8d generator; stands in for src/encode.py when no MLLM is present) ----
  * Fills a doc-major CSR of n vectors with `nnz` distinct terms each, drawn without replacement from
  * p(r) ~ r^-zipf_s over n_terms, weights max(1, rint(100*ln(1+x))), x ~ LogNormal(0.5, 0.6), clipped to [1,400].

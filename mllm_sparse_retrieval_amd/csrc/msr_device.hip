@@ -743,6 +743,8 @@ static int launch_score(hipStream_t st, uint32_t tile_docs, uint32_t ntiles, con
 #define MSR_LAUNCH(T, N, UU, W, WR)                                                                           \
     if (dump)                                                                                                 \
         hipLaunchKernelGGL((score_tiles<T, N, UU, WR, 512, false, 1>), dim3((uint32_t)blocks), dim3(N), 0, st, a); \
+    else if (a.dbg == 8u && a.k <= 512) /* stamps only: same shape as the production instance */             \
+        hipLaunchKernelGGL((score_tiles<T, N, UU, W, 512, true>), dim3((uint32_t)blocks), dim3(N), 0, st, a);   \
     else if (a.dbg)                                                                                           \
         hipLaunchKernelGGL((score_tiles<T, N, UU, WR, 1024, true>), dim3((uint32_t)blocks), dim3(N), 0, st, a); \
     else if (a.k <= 512)                                                                                      \
@@ -1816,6 +1818,234 @@ int msr_search_termshard_emulated(msr_index* ix, const int64_t* q_ptr, const int
     for (uint64_t* x : rank_part)
         if (x) (void)hipFree(x);
     cleanup();
+    return rc;
+}
+
+}  // extern "C"
+
+// ================================================================================================ dense (hybrid path)
+// Flat inner-product search over fp16 passage vectors: the dense half of the reference's hybrid search
+// (tevatron FaissFlatSearcher / faiss IndexFlatIP, fp16 storage on GPU: src/search.py:232-237,254-270; queries
+// normalised at src/search.py:342, corpus at src/encode.py:301). Scores C[q][d] = sum_k Q[q][k] * P[d][k] on MFMA
+// (v_mfma_f32_32x32x16_f16, f32 accumulate), written as order-preserving u32 keys into the accumulator layout of
+// select_tiles, so that top-`depth` selection and the tile merge are the SAME kernels as on the sparse path.
+namespace msr {
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef float float16v __attribute__((ext_vector_type(16)));
+
+__device__ __forceinline__ uint32_t f32_to_key(float f) {  // monotone: a < b  <=>  key(a) < key(b); never 0 for finite f
+    const uint32_t u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+
+// One workgroup = 4 waves = a 128 (queries) x 128 (docs) block; each wave owns 64 x 64 = 2 x 2 MFMA tiles and reads
+// its A/B fragments straight from the row-major fp16 matrices (lane (r, h) holds elements k0+8h .. k0+8h+7 of row r:
+// one 16-byte load). Q has Mpad rows, P has Npad rows (multiples of 128, zero padded), H is a multiple of 16.
+__global__ __launch_bounds__(256) void dense_scores(const _Float16* __restrict__ Q, const _Float16* __restrict__ P,
+                                                    uint32_t* __restrict__ out, uint32_t M, uint32_t N, uint32_t H,
+                                                    uint64_t ld) {
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t r = lane & 31, h = lane >> 5;
+    const uint32_t q_base = blockIdx.x * 128 + (wave >> 1) * 64;
+    const uint32_t d_base = blockIdx.y * 128 + (wave & 1) * 64;
+    float16v acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+    const _Float16* qa = Q + (uint64_t)(q_base + r) * H + 8 * h;
+    const _Float16* pb = P + (uint64_t)(d_base + r) * H + 8 * h;
+    const uint64_t step32 = (uint64_t)32 * H;
+    for (uint32_t k0 = 0; k0 < H; k0 += 16) {
+        const half8 a0 = *reinterpret_cast<const half8*>(qa + k0);
+        const half8 a1 = *reinterpret_cast<const half8*>(qa + step32 + k0);
+        const half8 b0 = *reinterpret_cast<const half8*>(pb + k0);
+        const half8 b1 = *reinterpret_cast<const half8*>(pb + step32 + k0);
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b0, acc[0][0], 0, 0, 0);
+        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b1, acc[0][1], 0, 0, 0);
+        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b0, acc[1][0], 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b1, acc[1][1], 0, 0, 0);
+    }
+    // C/D map of the 32x32 shapes: column = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const uint32_t d = d_base + 32 * j + r;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const uint32_t q = q_base + 32 * i + (e & 3) + 8 * (e >> 2) + 4 * h;
+                if (q < M) out[(uint64_t)q * ld + d] = d < N ? f32_to_key(acc[i][j][e]) : 0u;
+            }
+        }
+}
+
+}  // namespace msr
+
+struct msr_dense {
+    int device = -1;
+    hipStream_t stream = nullptr;
+    _Float16* d_P = nullptr;  // [n_pad][h]
+    uint64_t n = 0;
+    uint64_t n_pad = 0;       // multiple of 128 and of tile_docs
+    uint32_t h = 0;
+    uint32_t tile_docs = 0;
+    uint32_t n_tiles = 0;
+};
+
+extern "C" {
+
+int msr_dense_open(const uint16_t* p_fp16, uint64_t n, uint32_t h, int device, msr_dense** out) {
+    if (!out) {
+        set_error("msr_dense_open: null output");
+        return MSR_E_INVAL;
+    }
+    *out = nullptr;
+    if ((!p_fp16 && n) || h == 0 || h % 16 != 0 || n >= (1ull << 31)) {
+        set_error("msr_dense_open: need fp16 rows with a dimension that is a multiple of 16 (got n=%llu, h=%u)",
+                  (unsigned long long)n, h);
+        return MSR_E_INVAL;
+    }
+    int n_dev = 0;
+    if (device < 0 || hipGetDeviceCount(&n_dev) != hipSuccess || device >= n_dev) {
+        set_error("no usable HIP device %d; there is no CPU dense search path", device);
+        return MSR_E_NODEVICE;
+    }
+    msr_dense* dx = new (std::nothrow) msr_dense;
+    if (!dx) {
+        set_error("out of host memory");
+        return MSR_E_NOMEM;
+    }
+    dx->device = device;
+    dx->n = n;
+    dx->h = h;
+    dx->tile_docs = n <= 4096 ? 4096 : 8192;
+    dx->n_tiles = (uint32_t)std::max<uint64_t>((n + dx->tile_docs - 1) / dx->tile_docs, 1);
+    dx->n_pad = (uint64_t)dx->n_tiles * dx->tile_docs;
+    const size_t bytes = (size_t)dx->n_pad * h * 2;
+    if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&dx->stream, hipStreamNonBlocking) != hipSuccess ||
+        hipMalloc(&dx->d_P, bytes) != hipSuccess || hipMemset(dx->d_P, 0, bytes) != hipSuccess ||
+        (n && hipMemcpy(dx->d_P, p_fp16, (size_t)n * h * 2, hipMemcpyHostToDevice) != hipSuccess)) {
+        set_error("device setup of the dense index failed (%zu bytes)", bytes);
+        if (dx->d_P) (void)hipFree(dx->d_P);
+        if (dx->stream) (void)hipStreamDestroy(dx->stream);
+        delete dx;
+        return MSR_E_HIP;
+    }
+    *out = dx;
+    return MSR_OK;
+}
+
+void msr_dense_close(msr_dense* dx) {
+    if (!dx) return;
+    (void)hipSetDevice(dx->device);
+    if (dx->d_P) (void)hipFree(dx->d_P);
+    if (dx->stream) (void)hipStreamDestroy(dx->stream);
+    delete dx;
+}
+
+int msr_dense_search(msr_dense* dx, const uint16_t* q_fp16, int nq, int k, uint32_t* out_idx, uint32_t* out_key,
+                     int32_t* out_n, float* gemm_ms, float* select_ms) {
+    if (!dx || nq < 0 || (nq && !q_fp16) || !out_idx || !out_key || !out_n) {
+        set_error("msr_dense_search: bad argument");
+        return MSR_E_INVAL;
+    }
+    if (k < 1 || k > MSR_KMAX) {
+        set_error("k must be in [1, %d] (got %d)", MSR_KMAX, k);
+        return MSR_E_RANGE;
+    }
+    HIP_TRY(hipSetDevice(dx->device));
+    const uint32_t QT = 8192;  // queries per pass: scores buffer QT x n_pad u32
+    const uint32_t qt = (uint32_t)std::min<uint32_t>(QT, std::max(nq, 1));
+    const uint32_t qt_pad = (qt + 127) / 128 * 128;
+    _Float16* d_Q = nullptr;
+    uint32_t* d_S = nullptr;
+    uint64_t *d_part = nullptr;
+    uint32_t *d_ord = nullptr, *d_su = nullptr;
+    float* d_sf = nullptr;
+    int32_t* d_n = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr;
+    int rc = MSR_OK;
+    const size_t perq = std::max<size_t>((size_t)qt * k, 1);
+    bool ok = hipMalloc(&d_Q, (size_t)qt_pad * dx->h * 2) == hipSuccess &&
+              hipMalloc(&d_S, (size_t)qt_pad * dx->n_pad * 4) == hipSuccess &&
+              hipMalloc(&d_part, (size_t)dx->n_tiles * perq * 8) == hipSuccess && hipMalloc(&d_ord, perq * 4) == hipSuccess &&
+              hipMalloc(&d_su, perq * 4) == hipSuccess && hipMalloc(&d_sf, perq * 4) == hipSuccess &&
+              hipMalloc(&d_n, (size_t)qt * 4) == hipSuccess && hipEventCreate(&e0) == hipSuccess &&
+              hipEventCreate(&e1) == hipSuccess && hipEventCreate(&e2) == hipSuccess;
+    if (!ok) {
+        set_error("hipMalloc failed in msr_dense_search (%u queries per pass x %llu docs)", qt, (unsigned long long)dx->n_pad);
+        rc = MSR_E_NOMEM;
+    }
+    double t_gemm = 0, t_sel = 0;
+    for (int q0 = 0; q0 < nq && rc == MSR_OK; q0 += (int)qt) {
+        const uint32_t qn = (uint32_t)std::min<int>((int)qt, nq - q0);
+        const uint32_t qn_pad = (qn + 127) / 128 * 128;
+        bool c = hipMemsetAsync(d_Q, 0, (size_t)qn_pad * dx->h * 2, dx->stream) == hipSuccess &&
+                 hipMemcpyAsync(d_Q, q_fp16 + (size_t)q0 * dx->h, (size_t)qn * dx->h * 2, hipMemcpyHostToDevice,
+                                dx->stream) == hipSuccess &&
+                 hipEventRecord(e0, dx->stream) == hipSuccess;
+        if (!c) {
+            set_error("query upload failed in msr_dense_search");
+            rc = MSR_E_HIP;
+            break;
+        }
+        hipLaunchKernelGGL(dense_scores, dim3(qn_pad / 128, (uint32_t)(dx->n_pad / 128)), dim3(256), 0, dx->stream, d_Q,
+                           dx->d_P, d_S, qn, (uint32_t)dx->n, dx->h, dx->n_pad);
+        (void)hipEventRecord(e1, dx->stream);
+        SelectArgs se;
+        se.src = d_S;
+        se.part = d_part;
+        se.n_docs = dx->n;
+        se.n_tiles = dx->n_tiles;
+        se.tpr = dx->n_tiles;
+        se.rank = 0;
+        se.nq = qn;
+        se.q0 = 0;
+        se.qn = qn;
+        se.k = (uint32_t)k;
+        rc = launch_select(dx->stream, dx->tile_docs, se);
+        if (rc != MSR_OK) break;
+        MergeArgs ma;
+        ma.lists = d_part;
+        ma.list_stride = (uint64_t)qn * k;
+        ma.n_lists = dx->n_tiles;
+        ma.nq = qn;
+        ma.k = (uint32_t)k;
+        ma.out_keys = nullptr;
+        ma.out_ord = d_ord;
+        ma.out_score_u32 = d_su;
+        ma.out_score = d_sf;
+        ma.out_n = d_n;
+        rc = launch_merge(dx->stream, ma);
+        if (rc != MSR_OK) break;
+        (void)hipEventRecord(e2, dx->stream);
+        c = hipMemcpyAsync(out_idx + (size_t)q0 * k, d_ord, (size_t)qn * k * 4, hipMemcpyDeviceToHost, dx->stream) == hipSuccess &&
+            hipMemcpyAsync(out_key + (size_t)q0 * k, d_su, (size_t)qn * k * 4, hipMemcpyDeviceToHost, dx->stream) == hipSuccess &&
+            hipMemcpyAsync(out_n + q0, d_n, (size_t)qn * 4, hipMemcpyDeviceToHost, dx->stream) == hipSuccess &&
+            hipStreamSynchronize(dx->stream) == hipSuccess;
+        if (!c) {
+            set_error("dense search kernels or result download failed: %s", hipGetErrorString(hipGetLastError()));
+            rc = MSR_E_HIP;
+            break;
+        }
+        float a = 0, b2 = 0;
+        (void)hipEventElapsedTime(&a, e0, e1);
+        (void)hipEventElapsedTime(&b2, e1, e2);
+        t_gemm += a;
+        t_sel += b2;
+    }
+    if (gemm_ms) *gemm_ms = (float)t_gemm;
+    if (select_ms) *select_ms = (float)t_sel;
+    void* ptrs[] = {d_Q, d_S, d_part, d_ord, d_su, d_sf, d_n};
+    for (void* p : ptrs)
+        if (p) (void)hipFree(p);
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    if (e2) (void)hipEventDestroy(e2);
     return rc;
 }
 

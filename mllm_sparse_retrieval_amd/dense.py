@@ -1,0 +1,117 @@
+"""Dense half of the reference's hybrid search: flat inner product over passage vectors, top-`depth`.
+
+Drop-in for tevatron's FaissFlatSearcher as src/search.py uses it:
+    dense_retriever = FaissFlatSearcher(p_reps_0); dense_retriever.add(p_reps_0)        src/search.py:232-237
+    all_scores, all_indices = retriever.batch_search(q_reps, depth, batch_size, quiet)  src/search.py:57
+    (or retriever.search(q_reps, depth), src/search.py:59)
+The reference keeps the vectors in fp16 on the GPU (co.useFloat16, src/search.py:257,267); so does this class, with
+f32 accumulation on MFMA (msr_dense_search). Ties in score are broken by the lower row index.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from ._cabi import check, lib, ptr
+
+
+def keys_to_f32(keys):
+    """Inverse of the order-preserving f32 -> u32 map of the kernels (include/msr.h); key 0 (padding) -> -inf."""
+    keys = np.asarray(keys, dtype=np.uint32)
+    bits = np.where(keys & np.uint32(0x80000000), keys & np.uint32(0x7FFFFFFF), ~keys)
+    out = bits.astype(np.uint32).view(np.float32).copy()
+    out[keys == 0] = -np.inf
+    return out
+
+
+def _as_fp16_rows(x, dim=None):
+    x = np.asarray(x)
+    if x.ndim != 2:
+        raise ValueError("expected a [rows, dim] matrix")
+    h = x.shape[1]
+    pad = (-h) % 16
+    if dim is not None and h != dim:
+        raise ValueError(f"dimension mismatch: {h} vs {dim}")
+    x16 = x.astype(np.float16)
+    if pad:
+        x16 = np.concatenate([x16, np.zeros((x16.shape[0], pad), np.float16)], axis=1)
+    return np.ascontiguousarray(x16)
+
+
+class DenseIndex:
+    """fp16 passage matrix resident in HBM."""
+
+    def __init__(self, p_reps, device=0):
+        p16 = _as_fp16_rows(p_reps)
+        self.dim = np.asarray(p_reps).shape[1]
+        self.n = p16.shape[0]
+        self._h = C.c_void_p()
+        check(lib().msr_dense_open(ptr(p16.view(np.uint16)), self.n, p16.shape[1], int(device), C.byref(self._h)))
+        self.last_ms = (0.0, 0.0)
+
+    def search(self, q_reps, k):
+        """-> (scores float32 [nq,k], indices int64 [nq,k]); rows past the hit count hold (-inf, -1) like faiss."""
+        q16 = _as_fp16_rows(q_reps, self.dim)
+        nq = q16.shape[0]
+        idx = np.empty((nq, k), dtype=np.uint32)
+        key = np.empty((nq, k), dtype=np.uint32)
+        n = np.zeros(nq, dtype=np.int32)
+        a, b = C.c_float(), C.c_float()
+        check(lib().msr_dense_search(self._h, ptr(q16.view(np.uint16)), nq, int(k), ptr(idx), ptr(key), ptr(n),
+                                     C.byref(a), C.byref(b)))
+        self.last_ms = (a.value, b.value)
+        valid = np.arange(k)[None, :] < n[:, None]
+        scores = np.where(valid, keys_to_f32(key), -np.inf).astype(np.float32)
+        indices = np.where(valid, idx.astype(np.int64), -1)
+        return scores, indices
+
+    def close(self):
+        if self._h:
+            lib().msr_dense_close(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class FaissFlatSearcher:
+    """Same call shape as tevatron.retriever.searcher.FaissFlatSearcher (src/search.py:10,232-237,57-59)."""
+
+    def __init__(self, init_reps, device=0):
+        self._dim = np.asarray(init_reps).shape[1]
+        self._parts = []
+        self._index = None
+        self._device = device
+
+    def add(self, p_reps):
+        p = np.asarray(p_reps, dtype=np.float32)
+        if p.shape[1] != self._dim:
+            raise ValueError("dimension mismatch")
+        self._parts.append(p)
+        if self._index is not None:
+            self._index.close()
+            self._index = None
+
+    def _ready(self):
+        if self._index is None:
+            if not self._parts:
+                raise RuntimeError("FaissFlatSearcher: no vectors were added")
+            self._index = DenseIndex(np.concatenate(self._parts, axis=0), device=self._device)
+        return self._index
+
+    def search(self, q_reps, k):
+        return self._ready().search(q_reps, k)
+
+    def batch_search(self, q_reps, k, batch_size, quiet=False):
+        q = np.asarray(q_reps)
+        ix = self._ready()
+        scores, indices = [], []
+        for i in range(0, q.shape[0], max(int(batch_size), 1)):
+            s, j = ix.search(q[i:i + batch_size], k)
+            scores.append(s)
+            indices.append(j)
+        return np.concatenate(scores, axis=0), np.concatenate(indices, axis=0)

@@ -309,3 +309,81 @@ def test_term_range_shards_rccl_single_rank(m, tmp_path):
             b2.search(10, sharded="terms")
         b2.close()
         ix.comm_destroy()
+
+
+# ------------------------------------------------------------------------------------------------ dense / hybrid
+def _unit_rows(rng, n, h):
+    x = rng.standard_normal((n, h)).astype(np.float32)
+    return x / np.linalg.norm(x, axis=1, keepdims=True)
+
+
+def _dense_oracle(q, p, k):
+    """numpy f32 inner products of the fp16-ROUNDED inputs (the storage precision of the reference's GPU faiss,
+    src/search.py:257), ranked by (-score, row). Tolerance on scores: 1e-5 (f32 accumulation order)."""
+    s = q.astype(np.float16).astype(np.float32) @ p.astype(np.float16).astype(np.float32).T
+    order = np.lexsort((np.broadcast_to(np.arange(s.shape[1]), s.shape), -s), axis=1)[:, :k]
+    return np.take_along_axis(s, order, axis=1), order
+
+
+@pytest.mark.parametrize("n,h,nq,k", [(5000, 256, 300, 1000), (700, 64, 130, 10), (20000, 128, 64, 100), (3, 16, 5, 10)])
+def test_dense_search_against_numpy(m, n, h, nq, k):
+    from mllm_sparse_retrieval_amd.dense import FaissFlatSearcher
+
+    rng = np.random.default_rng(n + h)
+    p, q = _unit_rows(rng, n, h), _unit_rows(rng, nq, h)
+    r = FaissFlatSearcher(p)
+    r.add(p)
+    scores, idx = r.batch_search(q, k, batch_size=97, quiet=True)
+    ws, wi = _dense_oracle(q, p, min(k, n))
+    kk = min(k, n)
+    assert np.abs(scores[:, :kk] - ws).max() <= 1e-5
+    assert (idx[:, kk:] == -1).all() and np.isneginf(scores[:, kk:]).all()
+    # row indices agree except where two scores are closer than the f32 accumulation noise
+    diff = idx[:, :kk] != wi
+    if diff.any():
+        gap = np.abs(ws - np.take_along_axis(q.astype(np.float16).astype(np.float32)
+                                             @ p.astype(np.float16).astype(np.float32).T, idx[:, :kk], axis=1))
+        assert gap[diff].max() <= 2e-6 and diff.mean() < 0.01
+    assert (np.diff(scores[:, :kk], axis=1) <= 0).all()
+
+
+def test_hybrid_fusion_end_to_end(m, tmp_path):
+    """Config-5 shape in small: sparse top-depth + dense top-depth -> get_run_dict -> fuse, against the same pipeline
+    driven by the oracles (sparse: C port; dense: numpy on fp16-rounded inputs). Fused scores within 1e-5."""
+    from types import SimpleNamespace
+
+    from mllm_sparse_retrieval_amd.compat import FaissFlatSearcher, fuse, get_run_dict, search_queries
+    from oracle import oracle
+
+    n, nq, depth, n_terms, h = 3000, 100, 200, 2000, 128
+    docs, (qp, qt, qw) = helpers.synth(n, 64, nq, 40, n_terms, seed=55)
+    ids = [str(10000 + i) for i in range(n)]
+    path = m.build_index_from_csr(str(tmp_path / "h.idx"), *docs, n_terms, doc_ids=ids)
+    rng = np.random.default_rng(5)
+    p, q = _unit_rows(rng, n, h), _unit_rows(rng, nq, h)
+    qids = [str(i) for i in range(nq)]
+    with m.SparseIndex(path, device=0) as ix:
+        o, f, _, cnt = ix.search_csr(qp, qt, qw, depth)
+        s_scores = [[float(x) for x in f[i, :cnt[i]]] for i in range(nq)]
+        s_rank = [ix.docids(o[i, :cnt[i]]) for i in range(nq)]
+    sparse_run = get_run_dict(qids, s_scores, s_rank, False)
+    dr = FaissFlatSearcher(p)
+    dr.add(p)
+    d_scores, d_ids = search_queries(dr, q, ids, SimpleNamespace(batch_size=64, depth=depth, quiet=True))
+    dense_run = get_run_dict(qids, d_scores, d_ids, False)
+    fused = fuse([dense_run, sparse_run], [0.5, 0.5])
+    # oracle pipeline
+    oix, order = helpers.taat_oracle(docs, n_terms, ids)
+    wo, ws, wn = oix.search(qp, qt, qw, depth, threads=8)
+    sorted_ids = [ids[r] for r in order]
+    o_sparse = oracle.get_run_dict(qids, [[float(np.float32(x)) for x in ws[i, :wn[i]]] for i in range(nq)],
+                                   [[sorted_ids[int(d)] for d in wo[i, :wn[i]]] for i in range(nq)], False)
+    dsc, didx = _dense_oracle(q, p, depth)
+    o_dense = oracle.get_run_dict(qids, dsc, np.array([[ids[j] for j in row] for row in didx]), False)
+    want = oracle.fuse([o_dense, o_sparse], [0.5, 0.5])
+    worst = 0.0
+    for qid in qids:
+        common = set(fused[qid]) & set(want[qid])
+        assert len(common) >= 0.99 * len(want[qid])          # fp16-tie neighbours at the depth boundary may differ
+        worst = max(worst, max(abs(float(fused[qid][d]) - float(want[qid][d])) for d in common))
+    assert worst <= 1e-5
