@@ -171,6 +171,15 @@ int msr_dense_search(msr_dense* dx, const uint16_t* q_fp16, int nq, int k, uint3
                      int32_t* out_n, float* gemm_ms, float* select_ms);
 void msr_dense_close(msr_dense* dx);
 
+/* ---- hybrid search on the GPU: sparse top-`depth` + dense top-`depth` + the reference's min-max fusion
+ * (fuse, src/hybrid.py:32-53, weights [alpha, 1-alpha] src/search.py:459) + top-k, without leaving HBM in between.
+ * row2ord[r] = sparse doc ordinal of dense row r; self_ord[q] (nullable) = ordinal removed from query q's lists
+ * (remove_query, src/search.py:72-74) or -1. ms (nullable) = {sparse, dense GEMM, dense select, fusion} kernel ms. */
+int msr_hybrid_search(msr_index* ix, msr_dense* dx, const int64_t* q_ptr, const int32_t* q_term, const int32_t* q_w,
+                      const uint16_t* q_fp16, int nq, int depth, int k, float alpha, uint32_t flags,
+                      const uint32_t* row2ord, const int32_t* self_ord, uint32_t* out_ord, float* out_score, int32_t* out_n,
+                      float ms[4]);
+
 /* ---- synthetic encode step (SURVEY.md §8d generator; stands in for src/encode.py when no MLLM is present) ----
  * Fills a doc-major CSR of n vectors with `nnz` distinct terms each, drawn without replacement from
  * p(r) ~ r^-zipf_s over n_terms, weights max(1, rint(100*ln(1+x))), x ~ LogNormal(0.5, 0.6), clipped to [1,400].

@@ -1947,8 +1947,9 @@ void msr_dense_close(msr_dense* dx) {
     delete dx;
 }
 
-int msr_dense_search(msr_dense* dx, const uint16_t* q_fp16, int nq, int k, uint32_t* out_idx, uint32_t* out_key,
-                     int32_t* out_n, float* gemm_ms, float* select_ms) {
+// to_device = true: out_* are DEVICE buffers ([nq][k] / [nq]) filled on dx->stream (hybrid path); else host buffers.
+static int dense_search_impl(msr_dense* dx, const uint16_t* q_fp16, int nq, int k, uint32_t* out_idx, uint32_t* out_key,
+                             int32_t* out_n, float* gemm_ms, float* select_ms, bool to_device) {
     if (!dx || nq < 0 || (nq && !q_fp16) || !out_idx || !out_key || !out_n) {
         set_error("msr_dense_search: bad argument");
         return MSR_E_INVAL;
@@ -2023,9 +2024,10 @@ int msr_dense_search(msr_dense* dx, const uint16_t* q_fp16, int nq, int k, uint3
         rc = launch_merge(dx->stream, ma);
         if (rc != MSR_OK) break;
         (void)hipEventRecord(e2, dx->stream);
-        c = hipMemcpyAsync(out_idx + (size_t)q0 * k, d_ord, (size_t)qn * k * 4, hipMemcpyDeviceToHost, dx->stream) == hipSuccess &&
-            hipMemcpyAsync(out_key + (size_t)q0 * k, d_su, (size_t)qn * k * 4, hipMemcpyDeviceToHost, dx->stream) == hipSuccess &&
-            hipMemcpyAsync(out_n + q0, d_n, (size_t)qn * 4, hipMemcpyDeviceToHost, dx->stream) == hipSuccess &&
+        const hipMemcpyKind kind = to_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
+        c = hipMemcpyAsync(out_idx + (size_t)q0 * k, d_ord, (size_t)qn * k * 4, kind, dx->stream) == hipSuccess &&
+            hipMemcpyAsync(out_key + (size_t)q0 * k, d_su, (size_t)qn * k * 4, kind, dx->stream) == hipSuccess &&
+            hipMemcpyAsync(out_n + q0, d_n, (size_t)qn * 4, kind, dx->stream) == hipSuccess &&
             hipStreamSynchronize(dx->stream) == hipSuccess;
         if (!c) {
             set_error("dense search kernels or result download failed: %s", hipGetErrorString(hipGetLastError()));
@@ -2046,6 +2048,252 @@ int msr_dense_search(msr_dense* dx, const uint16_t* q_fp16, int nq, int k, uint3
     if (e0) (void)hipEventDestroy(e0);
     if (e1) (void)hipEventDestroy(e1);
     if (e2) (void)hipEventDestroy(e2);
+    return rc;
+}
+
+int msr_dense_search(msr_dense* dx, const uint16_t* q_fp16, int nq, int k, uint32_t* out_idx, uint32_t* out_key,
+                     int32_t* out_n, float* gemm_ms, float* select_ms) {
+    return dense_search_impl(dx, q_fp16, nq, k, out_idx, out_key, out_n, gemm_ms, select_ms, false);
+}
+
+}  // extern "C"
+
+// ================================================================================================ hybrid fusion
+// The reference's fuse() (src/hybrid.py:32-53) on the GPU: per query, over the union of the dense and the sparse
+// top-`depth` lists,  fused(doc) = w_dense * (d - min_d) / max(max_d - min_d, 1e-9)   [if the dense list holds doc]
+//                                + w_sparse * (s - min_s) / max(max_s - min_s, 1e-9)  [if the sparse list holds doc]
+// with min/max over each UNFILTERED list (get_run_dict, src/search.py:76-81) and the query's own doc skipped when
+// remove_query is set (src/search.py:72-74). Fused scores are built in an LDS accumulator tile over doc ordinals and
+// the best k are selected by the same tile_select as everywhere else. f32 arithmetic (the reference mixes f32 and
+// f64 depending on the numpy version): scores agree within the north star's 1e-5.
+namespace msr {
+
+struct FuseArgs {
+    const uint64_t* s_keys;   // [nq][depth] sparse keys (score<<32 | ~ordinal), best first, 0 padded
+    const uint32_t* d_idx;    // [nq][depth] dense row indices, best first
+    const uint32_t* d_key;    // [nq][depth] order-preserving keys of the dense f32 scores, 0 padded
+    const int32_t* d_n;       // [nq]
+    const uint32_t* row2ord;  // dense row -> sparse doc ordinal
+    const int32_t* self_ord;  // [nq] ordinal to skip (remove_query) or -1; may be null
+    uint64_t* part;           // [n_tiles][nq][k]
+    uint64_t n_docs;
+    uint32_t nq, depth, k;
+    float w_dense, w_sparse;
+};
+
+__device__ __forceinline__ float key_to_f32(uint32_t key) {
+    return __uint_as_float((key & 0x80000000u) ? (key & 0x7FFFFFFFu) : ~key);
+}
+
+template <int TILE_DOCS, int NT, int CAND>
+__global__ __launch_bounds__(NT) void fuse_tiles(const FuseArgs a) {
+    using L = TileLds<TILE_DOCS, NT, CAND>;
+    __shared__ __attribute__((aligned(16))) uint8_t lds[L::kTotal];
+    __shared__ uint8_t member[TILE_DOCS];
+    __shared__ float mm[4];  // min_s, den_s, min_d, den_d
+    uint32_t* const acc = reinterpret_cast<uint32_t*>(lds);
+    float* const facc = reinterpret_cast<float*>(lds);
+    uint8_t* const un = lds + L::kAcc;
+    uint64_t* const cand = reinterpret_cast<uint64_t*>(un);
+    uint32_t* const tmax = reinterpret_cast<uint32_t*>(un + L::kUnion);
+    uint32_t* const wmax = tmax + NT;
+    SelectScratch& ss = *reinterpret_cast<SelectScratch*>(un + L::kUnion + L::kTmax);
+    const uint32_t tid = threadIdx.x;
+    const uint32_t tile = blockIdx.x / a.nq, q = blockIdx.x % a.nq;
+    const uint64_t doc0 = (uint64_t)tile * TILE_DOCS;
+    const uint32_t ndocs_tile = (uint32_t)min((uint64_t)TILE_DOCS, a.n_docs - doc0);
+    const int rounds = (int)((ndocs_tile + 4 * NT - 1) / (4 * NT));
+    const uint64_t* sk = a.s_keys + (uint64_t)q * a.depth;
+    const uint32_t* di = a.d_idx + (uint64_t)q * a.depth;
+    const uint32_t* dk = a.d_key + (uint64_t)q * a.depth;
+    const int32_t dn = a.d_n[q];
+    const uint32_t self = a.self_ord ? (uint32_t)a.self_ord[q] : 0xFFFFFFFFu;
+
+    for (int i = tid; i < rounds * 4 * NT; i += NT) {
+        facc[i] = 0.f;
+        member[i] = 0;
+    }
+    __shared__ uint32_t ns_sh;
+    if (tid < 64) ss.cnt[tid] = 0;
+    if (tid == 0) {
+        ss.n_cand = 0;
+        ss.tau0 = 1;
+        ss.smax = 0;
+        ns_sh = 0;
+    }
+    __syncthreads();
+    for (uint32_t j = tid; j < a.depth; j += NT)
+        if (sk[j]) atomicMax(&ns_sh, j + 1);  // sparse hit count = index after the last non-empty slot
+    __syncthreads();
+    if (tid == 0) {
+        // lists are best-first: max = first entry, min = last non-empty entry
+        const uint32_t ns = ns_sh;
+        const float smax = ns ? (float)(uint32_t)(sk[0] >> 32) : 0.f, smin = ns ? (float)(uint32_t)(sk[ns - 1] >> 32) : 0.f;
+        const float dmax = dn > 0 ? key_to_f32(dk[0]) : 0.f, dmin = dn > 0 ? key_to_f32(dk[dn - 1]) : 0.f;
+        mm[0] = smin;
+        mm[1] = fmaxf(smax - smin, 1e-9f);
+        mm[2] = dmin;
+        mm[3] = fmaxf(dmax - dmin, 1e-9f);
+    }
+    __syncthreads();
+    // dense pass first (the reference adds the dense term first), then the sparse pass; docs are unique per list
+    for (int j = tid; j < dn; j += NT) {
+        const uint32_t ord = a.row2ord[di[j]];
+        if (ord != self && ord >= doc0 && ord < doc0 + ndocs_tile) {
+            facc[ord - doc0] = a.w_dense * ((key_to_f32(dk[j]) - mm[2]) / mm[3]);
+            member[ord - doc0] = 1;
+        }
+    }
+    __syncthreads();
+    for (uint32_t j = tid; j < a.depth; j += NT) {
+        const uint64_t key = sk[j];
+        if (!key) continue;
+        const uint32_t ord = 0xFFFFFFFFu - (uint32_t)key;
+        if (ord != self && ord >= doc0 && ord < doc0 + ndocs_tile) {
+            facc[ord - doc0] += a.w_sparse * (((float)(uint32_t)(key >> 32) - mm[0]) / mm[1]);
+            member[ord - doc0] = 1;
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < rounds * 4 * NT; i += NT) acc[i] = member[i] ? f32_to_key(facc[i]) : 0u;
+    __syncthreads();
+    tile_select<TILE_DOCS, NT, CAND>(reinterpret_cast<const uint4*>(lds), cand, tmax, wmax, ss, rounds, doc0, (int)a.k,
+                                     a.part + ((uint64_t)tile * a.nq + q) * a.k, [](int) {});
+}
+
+}  // namespace msr
+
+extern "C" {
+
+int msr_hybrid_search(msr_index* ix, msr_dense* dx, const int64_t* q_ptr, const int32_t* q_term, const int32_t* q_w,
+                      const uint16_t* q_fp16, int nq, int depth, int k, float alpha, uint32_t flags,
+                      const uint32_t* row2ord, const int32_t* self_ord, uint32_t* out_ord, float* out_score, int32_t* out_n,
+                      float ms[4]) {
+    if (!ix || !dx || !row2ord || !out_ord || !out_score || !out_n || nq < 0) {
+        set_error("msr_hybrid_search: bad argument");
+        return MSR_E_INVAL;
+    }
+    if (!ix->dev) {
+        set_error("index handle has no HIP device bound; there is no CPU scoring path");
+        return MSR_E_NODEVICE;
+    }
+    if (ix->dev->device != dx->device) {
+        set_error("the sparse and the dense index live on different devices");
+        return MSR_E_INVAL;
+    }
+    if (depth < 1 || depth > MSR_KMAX || k < 1 || k > MSR_KMAX) {
+        set_error("depth and k must be in [1, %d]", MSR_KMAX);
+        return MSR_E_RANGE;
+    }
+    if (dx->n != ix->host.h->n_docs) {
+        set_error("the dense index holds %llu rows but the sparse index %llu docs", (unsigned long long)dx->n,
+                  (unsigned long long)ix->host.h->n_docs);
+        return MSR_E_INVAL;
+    }
+    DeviceIndex* d = ix->dev;
+    const IndexHeader* h = ix->host.h;
+    msr_batch* b = nullptr;
+    int rc = msr_batch_create(ix, q_ptr, q_term, q_w, nq, depth, flags, &b);
+    if (rc != MSR_OK) return rc;
+    uint32_t *d_didx = nullptr, *d_dkey = nullptr, *d_map = nullptr, *d_ord = nullptr, *d_su = nullptr;
+    int32_t *d_dn = nullptr, *d_self = nullptr, *d_n = nullptr;
+    float* d_sf = nullptr;
+    uint64_t* d_part = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    const uint32_t ftile = h->n_docs <= 4096 ? 4096 : 8192;
+    const uint32_t ftiles = (uint32_t)std::max<uint64_t>((h->n_docs + ftile - 1) / ftile, 1);
+    const size_t per = std::max<size_t>((size_t)nq * depth, 1), perk = std::max<size_t>((size_t)nq * k, 1);
+    bool ok = hipSetDevice(d->device) == hipSuccess && hipMalloc(&d_didx, per * 4) == hipSuccess &&
+              hipMalloc(&d_dkey, per * 4) == hipSuccess && hipMalloc(&d_dn, std::max<size_t>(nq, 1) * 4) == hipSuccess &&
+              hipMalloc(&d_map, std::max<size_t>(h->n_docs, 1) * 4) == hipSuccess &&
+              hipMalloc(&d_part, (size_t)ftiles * perk * 8) == hipSuccess && hipMalloc(&d_ord, perk * 4) == hipSuccess &&
+              hipMalloc(&d_su, perk * 4) == hipSuccess && hipMalloc(&d_sf, perk * 4) == hipSuccess &&
+              hipMalloc(&d_n, std::max<size_t>(nq, 1) * 4) == hipSuccess && hipEventCreate(&e0) == hipSuccess &&
+              hipEventCreate(&e1) == hipSuccess &&
+              hipMemcpy(d_map, row2ord, (size_t)h->n_docs * 4, hipMemcpyHostToDevice) == hipSuccess;
+    if (ok && self_ord)
+        ok = hipMalloc(&d_self, std::max<size_t>(nq, 1) * 4) == hipSuccess &&
+             hipMemcpy(d_self, self_ord, (size_t)nq * 4, hipMemcpyHostToDevice) == hipSuccess;
+    if (!ok) {
+        set_error("device allocation failed in msr_hybrid_search");
+        rc = MSR_E_NOMEM;
+    }
+    float t_gemm = 0, t_sel = 0, t_sparse = 0, t_merge = 0, t_fuse = 0;
+    if (rc == MSR_OK) rc = batch_search_local(b, depth, false);  // sparse top-depth keys -> b->d_keys
+    if (rc == MSR_OK) rc = dense_search_impl(dx, q_fp16, nq, depth, d_didx, d_dkey, d_dn, &t_gemm, &t_sel, true);
+    if (rc == MSR_OK) {
+        (void)hipEventRecord(e0, d->stream);
+        FuseArgs fa;
+        fa.s_keys = b->d_keys;
+        fa.d_idx = d_didx;
+        fa.d_key = d_dkey;
+        fa.d_n = d_dn;
+        fa.row2ord = d_map;
+        fa.self_ord = d_self;
+        fa.part = d_part;
+        fa.n_docs = h->n_docs;
+        fa.nq = (uint32_t)nq;
+        fa.depth = (uint32_t)depth;
+        fa.k = (uint32_t)k;
+        fa.w_dense = alpha;
+        fa.w_sparse = 1.0f - alpha;
+        if (nq) {
+            if (ftile == 4096)
+                hipLaunchKernelGGL((fuse_tiles<4096, 256, 1024>), dim3(ftiles * (uint32_t)nq), dim3(256), 0, d->stream, fa);
+            else
+                hipLaunchKernelGGL((fuse_tiles<8192, 512, 1024>), dim3(ftiles * (uint32_t)nq), dim3(512), 0, d->stream, fa);
+        }
+        MergeArgs ma;
+        ma.lists = d_part;
+        ma.list_stride = (uint64_t)nq * k;
+        ma.n_lists = ftiles;
+        ma.nq = (uint32_t)nq;
+        ma.k = (uint32_t)k;
+        ma.out_keys = nullptr;
+        ma.out_ord = d_ord;
+        ma.out_score_u32 = d_su;
+        ma.out_score = d_sf;
+        ma.out_n = d_n;
+        rc = launch_merge(d->stream, ma);
+        (void)hipEventRecord(e1, d->stream);
+    }
+    if (rc == MSR_OK && hipStreamSynchronize(d->stream) != hipSuccess) {
+        set_error("hybrid kernels failed: %s", hipGetErrorString(hipGetLastError()));
+        rc = MSR_E_HIP;
+    }
+    if (rc == MSR_OK) {
+        (void)msr_batch_kernel_ms(b, &t_sparse, &t_merge);
+        (void)hipEventElapsedTime(&t_fuse, e0, e1);
+        // out_score: the fused f32 score is carried as an order-preserving key in the u32 score slot
+        std::vector<uint32_t> keys((size_t)nq * k);
+        bool c = (!nq) || (hipMemcpy(out_ord, d_ord, (size_t)nq * k * 4, hipMemcpyDeviceToHost) == hipSuccess &&
+                           hipMemcpy(keys.data(), d_su, (size_t)nq * k * 4, hipMemcpyDeviceToHost) == hipSuccess &&
+                           hipMemcpy(out_n, d_n, (size_t)nq * 4, hipMemcpyDeviceToHost) == hipSuccess);
+        if (!c) {
+            set_error("download failed in msr_hybrid_search");
+            rc = MSR_E_HIP;
+        } else {
+            for (size_t i = 0; i < keys.size(); ++i) {
+                const uint32_t key = keys[i];
+                uint32_t bits = (key & 0x80000000u) ? (key & 0x7FFFFFFFu) : ~key;
+                float f;
+                memcpy(&f, &bits, 4);
+                out_score[i] = key ? f : 0.f;
+            }
+        }
+    }
+    if (ms) {
+        ms[0] = t_sparse + t_merge;
+        ms[1] = t_gemm;
+        ms[2] = t_sel;
+        ms[3] = t_fuse;
+    }
+    void* ptrs[] = {d_didx, d_dkey, d_dn, d_map, d_self, d_part, d_ord, d_su, d_sf, d_n};
+    for (void* p : ptrs)
+        if (p) (void)hipFree(p);
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    batch_free(b);
     return rc;
 }
 

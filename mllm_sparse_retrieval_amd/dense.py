@@ -115,3 +115,34 @@ class FaissFlatSearcher:
             scores.append(s)
             indices.append(j)
         return np.concatenate(scores, axis=0), np.concatenate(indices, axis=0)
+
+
+def row_to_ordinal(sparse_index, lookup):
+    """dense row r carries external id lookup[r] (the pkl's lookup list, src/search.py:61) -> sparse doc ordinal."""
+    ord_of = {sparse_index.docid(o): o for o in range(sparse_index.n_docs)}
+    return np.asarray([ord_of[str(x)] for x in lookup], dtype=np.uint32)
+
+
+def hybrid_search(sparse_index, dense_index, q_ptr, q_term, q_w, q_reps, depth, k, alpha, row2ord, self_ord=None,
+                  drop_df_eq_n=True):
+    """Sparse top-`depth` + dense top-`depth` + min-max fusion (src/hybrid.py:32-53, weights [alpha, 1-alpha]) + top-k,
+    all on the GPU. -> (doc ordinals uint32 [nq,k], fused scores float32 [nq,k], n [nq], kernel ms per stage)."""
+    from . import _cabi
+    from ._cabi import MSR_F_DROP_DF_EQ_N
+
+    q_ptr, q_term, q_w = _cabi.as_csr(q_ptr, q_term, q_w)
+    q16 = _as_fp16_rows(q_reps, dense_index.dim)
+    nq = len(q_ptr) - 1
+    if q16.shape[0] != nq:
+        raise ValueError("sparse and dense query counts differ")
+    row2ord = np.ascontiguousarray(row2ord, dtype=np.uint32)
+    so = None if self_ord is None else np.ascontiguousarray(self_ord, dtype=np.int32)
+    ords = np.empty((nq, k), dtype=np.uint32)
+    sc = np.empty((nq, k), dtype=np.float32)
+    n = np.zeros(nq, dtype=np.int32)
+    ms = (C.c_float * 4)()
+    check(lib().msr_hybrid_search(sparse_index._h, dense_index._h, ptr(q_ptr), ptr(q_term), ptr(q_w),
+                                  ptr(q16.view(np.uint16)), nq, int(depth), int(k), float(alpha),
+                                  MSR_F_DROP_DF_EQ_N if drop_df_eq_n else 0, ptr(row2ord), ptr(so), ptr(ords), ptr(sc),
+                                  ptr(n), ms))
+    return ords, sc, n, dict(sparse=ms[0], dense_gemm=ms[1], dense_select=ms[2], fusion=ms[3])

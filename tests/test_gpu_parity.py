@@ -387,3 +387,46 @@ def test_hybrid_fusion_end_to_end(m, tmp_path):
         assert len(common) >= 0.99 * len(want[qid])          # fp16-tie neighbours at the depth boundary may differ
         worst = max(worst, max(abs(float(fused[qid][d]) - float(want[qid][d])) for d in common))
     assert worst <= 1e-5
+
+
+@pytest.mark.parametrize("n,alpha,remove", [(3000, 0.5, False), (9000, 0.3, True)])
+def test_gpu_fusion_matches_host_fuse(m, tmp_path, n, alpha, remove):
+    """msr_hybrid_search (everything on the GPU) against the reference-semantics host pipeline
+    get_run_dict + fuse (pinned to src/hybrid.py) fed with the same GPU lists: top-10 ids and fused scores (1e-5)."""
+    from types import SimpleNamespace
+
+    from mllm_sparse_retrieval_amd.compat import FaissFlatSearcher, fuse, get_run_dict, search_queries
+    from mllm_sparse_retrieval_amd.dense import DenseIndex, hybrid_search, row_to_ordinal
+
+    nq, depth, n_terms, h, k = 120, 300, 2000, 64, 10
+    docs, (qp, qt, qw) = helpers.synth(n, 64, nq, 40, n_terms, seed=n)
+    ids = [str(i) for i in range(n)]
+    path = m.build_index_from_csr(str(tmp_path / "f.idx"), *docs, n_terms, doc_ids=ids)
+    rng = np.random.default_rng(n)
+    p, q = _unit_rows(rng, n, h), _unit_rows(rng, nq, h)
+    qids = [str(i) for i in range(nq)]                        # query ids collide with doc ids -> remove_query matters
+    with m.SparseIndex(path, device=0) as ix:
+        dix = DenseIndex(p)
+        r2o = row_to_ordinal(ix, ids)
+        self_ord = np.array([int(r2o[int(x)]) for x in qids], dtype=np.int32) if remove else None
+        ords, fs, cnt, ms = hybrid_search(ix, dix, qp, qt, qw, q, depth, k, alpha, r2o, self_ord)
+        got_ids = [ix.docids(ords[i, :cnt[i]]) for i in range(nq)]
+        o, f, _, c = ix.search_csr(qp, qt, qw, depth)
+        sparse_run = get_run_dict(qids, [[float(x) for x in f[i, :c[i]]] for i in range(nq)],
+                                  [ix.docids(o[i, :c[i]]) for i in range(nq)], remove)
+        dix.close()
+    dr = FaissFlatSearcher(p)
+    dr.add(p)
+    d_scores, d_ids = search_queries(dr, q, ids, SimpleNamespace(batch_size=64, depth=depth, quiet=True))
+    dense_run = get_run_dict(qids, d_scores, d_ids, remove)
+    want = fuse([dense_run, sparse_run], [alpha, 1 - alpha])
+    assert ms["fusion"] > 0
+    for i, qid in enumerate(qids):
+        ranked = sorted(want[qid].items(), key=lambda kv: (-float(kv[1]), kv[0].encode()))[:k]
+        assert cnt[i] == len(ranked)
+        for j, (doc, score) in enumerate(ranked):
+            assert abs(float(fs[i, j]) - float(score)) <= 1e-5
+            if got_ids[i][j] != doc:   # only a near-tie in the fused score may swap neighbours
+                assert abs(float(want[qid][got_ids[i][j]]) - float(score)) <= 2e-6
+        if remove:
+            assert qid not in got_ids[i]
