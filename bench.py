@@ -341,6 +341,46 @@ def run_c4(args, ranks, m, wlmod):
     return out
 
 
+def run_c5(args, ranks, m):
+    """configs[4]: hybrid dense + sparse, COCO-5K t->i shape: N = 5 000 docs (128 nnz + 4096-d fp16 unit vectors),
+    25 010 queries (120 nnz + 4096-d), depth 1000 -> fused top-10, alpha 0.5 (scripts/search.sh:25,32). One GPU."""
+    from mllm_sparse_retrieval_amd.dense import DenseIndex, hybrid_search, row_to_ordinal
+
+    n, nq, h, depth, k, alpha, n_terms = args.c5_docs, args.c5_queries, 4096, 1000, 10, 0.5, 30000
+    docs = m.synth_vectors(n, 128, n_terms, seed=4, threads=args.host_threads)
+    qp, qt, qw = m.synth_vectors(nq, 120, n_terms, seed=5, threads=args.host_threads)
+    rng = np.random.default_rng(4)
+    p = rng.standard_normal((n, h), dtype=np.float32)
+    p /= np.linalg.norm(p, axis=1, keepdims=True)
+    q = rng.standard_normal((nq, h), dtype=np.float32)
+    q /= np.linalg.norm(q, axis=1, keepdims=True)
+    tmp = tempfile.mkdtemp(prefix="msr_c5_")
+    path = m.build_index_from_csr(os.path.join(tmp, "c5.idx"), *docs, n_terms, threads=args.host_threads)
+    ix = m.SparseIndex(path, device=ranks.local_rank)
+    dix = DenseIndex(p, device=ranks.local_rank)
+    r2o = row_to_ordinal(ix, [str(i) for i in range(n)])
+    hybrid_search(ix, dix, qp, qt, qw, q, depth, k, alpha, r2o)                      # warm-up
+    t0 = time.perf_counter()
+    ords, fs, cnt, ms = hybrid_search(ix, dix, qp, qt, qw, q, depth, k, alpha, r2o)
+    wall = time.perf_counter() - t0
+    kern = sum(ms.values())
+    out = {"workload": f"hybrid: {n} docs x (128 nnz + {h}-d fp16), {nq} queries x (120 nnz + {h}-d), depth {depth} -> "
+                       f"fused top-{k}, alpha {alpha}",
+           "value": round(nq / (kern * 1e-3), 1), "unit": "queries/s (kernel time, inputs resident)",
+           "host_inclusive_queries_per_s": round(nq / wall, 1),
+           "kernel_ms": {k2: round(v, 3) for k2, v in ms.items()},
+           "dense_tflops": round(2.0 * nq * n * h / (ms["dense_gemm"] * 1e-3) / 1e12, 1) if ms["dense_gemm"] > 0 else None,
+           "dtype": "f16 in / f32 accumulate (dense), u32 (sparse), f32 (fusion)"}
+    dix.close()
+    ix.close()
+    try:
+        os.remove(path)
+        os.rmdir(tmp)
+    except OSError:
+        pass
+    return out
+
+
 def main():
     # stdout carries exactly ONE JSON line: keep a private handle to it and point fd 1 at stderr, so that banners
     # printed by native libraries (RCCL prints its version block at communicator init) cannot pollute it
@@ -360,6 +400,10 @@ def main():
     ap.add_argument("--no-c4", action="store_true", help="skip the 1 M-doc extra object")
     ap.add_argument("--no-term-shards", action="store_true", help="skip the term-range sharded variant at N > 1")
     ap.add_argument("--only-c4", action="store_true", help="(profiling) run only the 1 M-doc workload")
+    ap.add_argument("--c5-docs", type=int, default=5000)
+    ap.add_argument("--c5-queries", type=int, default=25010)
+    ap.add_argument("--no-c5", action="store_true", help="skip the hybrid (config 5) extra object")
+    ap.add_argument("--only-c5", action="store_true", help="(profiling) run only the hybrid workload")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline / parity sample")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
     ap.add_argument("--cpu-threads", type=int, default=min(16, os.cpu_count() or 1))
@@ -376,9 +420,15 @@ def main():
         m.set_build_option("dense_min_density", args.dense_density)
 
     out = {}
-    if not args.only_c4:
+    if not args.only_c4 and not args.only_c5:
         out = run_headline(args, ranks, m, wlmod)
-    if not args.no_c4:
+    if ranks.world == 1 and not args.no_c5 and not args.only_c4:
+        try:
+            out["c5_hybrid"] = run_c5(args, ranks, m)
+        except Exception as e:
+            out["c5_hybrid"] = {"error": f"{type(e).__name__}: {e}"}
+            log(f"[bench] c5_hybrid failed: {out['c5_hybrid']['error']}")
+    if not args.no_c4 and not args.only_c5:
         try:
             c4 = run_c4(args, ranks, m, wlmod)
         except Exception as e:  # the extra object must never take the headline line down
