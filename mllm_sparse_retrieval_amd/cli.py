@@ -45,6 +45,20 @@ def _cmd_encode(a):
             toks = " ".join(" ".join([f"t{int(t)}"] * int(w)) for t, w in zip(qt[qp[i]:qp[i + 1]], qw[qp[i]:qp[i + 1]]))
             if toks.strip():
                 f.write(f"{i}\t{toks}\n")
+    if a.dense_output_dir:  # dense reps in the reference's pickle layout (reps, lookup) (src/encode.py:405-410)
+        import pickle
+
+        os.makedirs(a.dense_output_dir, exist_ok=True)
+        rng = np.random.default_rng(a.seed)
+        n_docs, n_q = len(dp) - 1, len(qp) - 1
+        p = rng.standard_normal((n_docs, a.dense_dim)).astype(np.float32)
+        # planted signal: a caption's vector is its image's vector plus noise
+        qv = p[np.arange(n_q) // 5] + 1.5 * rng.standard_normal((n_q, a.dense_dim)).astype(np.float32)
+        p /= np.linalg.norm(p, axis=1, keepdims=True)
+        with open(os.path.join(a.dense_output_dir, f"corpus_{a.dataset_shard_index}.pkl"), "wb") as f:
+            pickle.dump((p, [str(i) for i in range(n_docs)]), f)
+        with open(os.path.join(a.dense_output_dir, "query.pkl"), "wb") as f:
+            pickle.dump((qv, [str(i) for i in range(n_q)]), f)
     with open(os.path.join(out, "qrels.csv"), "w") as f:  # flickr csv schema (src/dataset.py:86-102)
         f.write("imgid,filename,caption,sentid\n")
         for i in range(len(qp) - 1):
@@ -90,28 +104,56 @@ def _cmd_search(a):
     from .run import get_run_dict, sparse_search
     from .searcher import JWhiteSpaceAnalyzer, LuceneImpactSearcher
 
-    if a.passage_reps is not None:
-        sys.exit("search: --passage_reps (dense / hybrid) is not available in this build yet; sparse only")
+    dense_retriever = p_lookup = q_reps_by_id = None
+    if a.passage_reps is not None:  # dense side of the hybrid search (src/search.py:227-237)
+        import glob
+
+        import numpy as np
+
+        from .dense import FaissFlatSearcher
+        from .run import pickle_load, search_queries
+
+        files = sorted(glob.glob(os.path.join(a.passage_reps, "corpus*.pkl")))
+        if not files:
+            sys.exit(f"search: no corpus*.pkl under {a.passage_reps}")
+        p_reps, p_lookup = pickle_load(files[0])     # files written by this package's own encode step
+        dense_retriever = FaissFlatSearcher(p_reps, device=a.device)
+        dense_retriever.add(p_reps)
+        q_reps, q_lookup = pickle_load(os.path.join(a.passage_reps, "query.pkl"))
+        q_reps_by_id = {str(i): r for i, r in zip(q_lookup, q_reps)}
     searcher = LuceneImpactSearcher(os.path.join(a.sparse_index, "index") if os.path.isdir(
         os.path.join(a.sparse_index, "index")) else a.sparse_index, None, device=a.device)
     searcher.set_analyzer(JWhiteSpaceAnalyzer())
     qids, texts = read_queries(a.queries or os.path.join(a.sparse_index, "query.tsv"))
     bs = a.batch_size if a.batch_size > 0 else len(qids)
     args = SimpleNamespace(depth=a.depth, threads=a.threads, query_type=a.query_type)
-    sparse_run = {}
+    sparse_run, dense_run, fusion_run = {}, {}, {}
+    args.batch_size, args.quiet = a.batch_size, True
     t0 = time.time()
     for i in range(0, len(qids), bs):
         scores, rankings = sparse_search(searcher, texts[i:i + bs], qids[i:i + bs], args)
         sparse_run.update(get_run_dict(qids[i:i + bs], scores, rankings, a.remove_query))
+        if dense_retriever is not None:
+            q = np.stack([q_reps_by_id[x] for x in qids[i:i + bs]])
+            q = q / np.maximum(np.linalg.norm(q, axis=1, keepdims=True), 1e-12)        # F.normalize, src/search.py:342
+            d_scores, d_ids = search_queries(dense_retriever, q, p_lookup, args)
+            dense_run.update(get_run_dict(qids[i:i + bs], d_scores, d_ids, a.remove_query))
+    if dense_retriever is not None:
+        from .fusion import fuse
+
+        fusion_run = fuse([dense_run, sparse_run], [a.alpha, 1 - a.alpha])             # src/search.py:455-461
     dt = time.time() - t0
     if not a.quiet:
         print(f"search: {len(qids)} queries in {dt:.3f}s ({len(qids) / max(dt, 1e-9):.0f} q/s end-to-end incl. host)")
     if a.save_dir:
         os.makedirs(a.save_dir, exist_ok=True)
         write_trec_run(sparse_run, os.path.join(a.save_dir, "sparse.trec"), name="sparse")
+        if dense_run:
+            write_trec_run(dense_run, os.path.join(a.save_dir, "dense.trec"), name="dense")
+            write_trec_run(fusion_run, os.path.join(a.save_dir, "fusion.trec"))
     if a.qrels:
         ds = CrossModalQrels(a.qrels, a.dataset_name)
-        m = RecallMetrics(ds, {}, sparse_run, {}, [], qids, args)
+        m = RecallMetrics(ds, dense_run, sparse_run, fusion_run, p_lookup or [], qids, args)
         m.sort_and_count()
         m.all_gather_object()
         m.print_recall()
@@ -124,6 +166,8 @@ def main(argv=None):
     e = sub.add_parser("encode")
     e.add_argument("--synthetic", choices=["flickr", "coco"])
     e.add_argument("--sparse_output_dir", default="./sparse_output/")
+    e.add_argument("--dense_output_dir", default=None)
+    e.add_argument("--dense_dim", type=int, default=256)
     e.add_argument("--dataset_shard_index", type=int, default=0)
     e.add_argument("--n_images", type=int, default=0)
     e.add_argument("--seed", type=int, default=1)

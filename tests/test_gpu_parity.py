@@ -229,6 +229,18 @@ def test_cli_search_end_to_end(m, tmp_path, capsys):
     assert 0.2 < r1 <= 1.0                                               # planted signal is found
     run = read_trec_run(str(tmp_path / "runs" / "sparse.trec"))
     assert len(run) == 1500 and all(len(v["docs"]) <= 10 for v in run.values())
+    # hybrid: dense reps next to the sparse files, --passage_reps switches dense + fusion on (scripts/search.sh)
+    dense = str(tmp_path / "dense")
+    cli.main(["encode", "--synthetic", "flickr", "--n_images", "300", "--sparse_output_dir", enc, "--threads", "4",
+              "--dense_output_dir", dense, "--dense_dim", "64"])
+    cli.main(["search", "--sparse_index", enc, "--passage_reps", dense, "--depth", "100", "--batch_size", "500",
+              "--alpha", "0.5", "--query_type", "text", "--dataset_name", "flickr",
+              "--qrels", os.path.join(enc, "qrels.csv"), "--save_dir", str(tmp_path / "runs2")])
+    out = capsys.readouterr().out
+    rec = {name: float([l for l in out.splitlines() if l.startswith(name)][0].split("r@10 ")[1].split(",")[0])
+           for name in ("Dense reps recall", "Sparse reps recall", "Fusion/Hybrid reps recall")}
+    assert rec["Fusion/Hybrid reps recall"] >= max(rec["Dense reps recall"], rec["Sparse reps recall"]) - 0.02
+    assert os.path.exists(tmp_path / "runs2" / "fusion.trec")
 
 
 # ------------------------------------------------------------------------------------------------ full-size properties
