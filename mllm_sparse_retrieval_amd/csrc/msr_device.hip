@@ -250,30 +250,53 @@ __device__ __forceinline__ void tile_select(const uint4* a4, uint64_t* cand, uin
     uint32_t n_cand = ss.n_cand;
 
     if (n_cand > CAND) {
-        // ---- fallback: bisection for the k-th largest (score, ordinal) key of the whole tile.
-        // local key = score << 16 | (0xFFFF - local ordinal): unique, so exactly min(k, #positive) survive.
+        // ---- fallback (mass ties, or k in the hundreds): exact selection by bisection.
+        //   1. tau = k-th largest SCORE of the tile: one bit per step, counted with ballots (scalar popcounts);
+        //   2. every accumulator above tau is in; of the c_eq accumulators equal to tau the `need` lowest ordinals are
+        //      in — found by a second bisection over the local ordinal only when there are more ties than needed.
+        // Exactly min(k, #positive) <= CAND keys survive.
         __syncthreads();  // everyone has read n_cand
         if (tid == 0) ss.n_cand = 0;
-        const int top = 16 + (32 - __clz(smax));  // bits in use (<= 48 < 64 counter slots)
-        uint64_t tau = 0;
-        int step = 0;
-        for (int bit = top - 1; bit >= 0; --bit, ++step) {
-            const uint64_t t2 = tau | (1ull << bit);
+        auto count_if = [&](auto pred) -> uint32_t {  // wave-level count over this wave's accumulators (uniform)
             uint32_t c = 0;
             for (int r = 0; r < rounds; ++r) {
                 const uint4 x = a4[r * NT + tid];
-                const uint32_t sc4[4] = {x.x, x.y, x.z, x.w};
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const uint32_t local = 4 * (r * NT + tid) + e;
-                    const uint64_t key = sc4[e] ? (((uint64_t)sc4[e] << 16) | (0xFFFFu - local)) : 0ull;
-                    c += key >= t2;
-                }
+                const uint32_t base = 4 * (r * NT + tid);
+                c += (uint32_t)__popcll(__ballot(pred(x.x, base))) + (uint32_t)__popcll(__ballot(pred(x.y, base + 1))) +
+                     (uint32_t)__popcll(__ballot(pred(x.z, base + 2))) + (uint32_t)__popcll(__ballot(pred(x.w, base + 3)));
             }
-            c = wave_sum_u32(c);
+            return c;
+        };
+        int step = 0;
+        auto block_count = [&](uint32_t c) -> uint32_t {  // sum of the waves' counts, the same value on every thread
             if (lane == 0 && c) atomicAdd(&ss.cnt[step], c);
             __syncthreads();
-            if (ss.cnt[step] >= (uint32_t)k) tau = t2;
+            return ss.cnt[step++];
+        };
+        uint32_t tau = 0;
+        for (int bit = 31 - __clz(smax); bit >= 0; --bit) {
+            const uint32_t t2 = tau | (1u << bit);
+            if (block_count(count_if([&](uint32_t sc, uint32_t) { return sc >= t2; })) >= (uint32_t)k) tau = t2;
+        }
+        uint32_t o_star = 0xFFFFFFFFu;  // ties at tau with local ordinal <= o_star are selected
+        if (tau == 0) {
+            tau = 1;  // fewer than k positive accumulators: all of them
+        } else {
+            const uint32_t c_gt = block_count(count_if([&](uint32_t sc, uint32_t) { return sc > tau; }));
+            const uint32_t c_eq = block_count(count_if([&](uint32_t sc, uint32_t) { return sc == tau; }));
+            const uint32_t need = (uint32_t)k - c_gt;  // >= 1 by the definition of tau
+            if (c_eq > need) {
+                uint32_t lo = 0, hi = TILE_DOCS - 1;  // smallest o with #(ties, local <= o) >= need
+                while (lo < hi) {
+                    const uint32_t mid = (lo + hi) >> 1;
+                    const uint32_t c = block_count(count_if([&](uint32_t sc, uint32_t loc) { return sc == tau && loc <= mid; }));
+                    if (c >= need)
+                        hi = mid;
+                    else
+                        lo = mid + 1;
+                }
+                o_star = lo;
+            }
         }
         __syncthreads();
         for (int r = 0; r < rounds; ++r) {
@@ -282,8 +305,7 @@ __device__ __forceinline__ void tile_select(const uint4* a4, uint64_t* cand, uin
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const uint32_t local = 4 * (r * NT + tid) + e;
-                const uint64_t key = sc4[e] ? (((uint64_t)sc4[e] << 16) | (0xFFFFu - local)) : 0ull;
-                if (key && key >= tau) {
+                if (sc4[e] > tau || (sc4[e] == tau && local <= o_star)) {
                     const uint32_t pos = atomicAdd(&ss.n_cand, 1u);
                     if (pos < CAND)
                         cand[pos] = ((uint64_t)sc4[e] << 32) | (uint64_t)(0xFFFFFFFFu - (uint32_t)(doc0 + local));
