@@ -93,13 +93,17 @@ class Ranks:
             self.dist.destroy_process_group()
 
 
+_SYNC_DEVICE = 0
+
+
 def device_sync():
-    """Contract: torch.cuda.synchronize() on both sides of the timed region (device-wide, covers libmsr's stream)."""
+    """Contract: torch.cuda.synchronize() on both sides of the timed region (device-wide, covers libmsr's stream).
+    Always on THIS rank's GPU: a bare synchronize() would create a context on GPU 0 from every rank."""
     try:
         import torch
 
         if torch.cuda.is_available():
-            torch.cuda.synchronize()
+            torch.cuda.synchronize(_SYNC_DEVICE)
     except Exception:
         pass
 
@@ -411,6 +415,8 @@ def main():
     args = ap.parse_args()
 
     ranks = Ranks(args.gpus)
+    global _SYNC_DEVICE
+    _SYNC_DEVICE = ranks.local_rank
     import mllm_sparse_retrieval_amd as m  # raises if libmsr.so is missing: there is no fallback scorer
     from mllm_sparse_retrieval_amd import workloads as wlmod
 
