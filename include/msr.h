@@ -162,7 +162,7 @@ int msr_merge_lists(msr_index* ix, int n_lists, int nq, int k, const uint32_t* d
 
 /* ---- dense flat inner-product search (hybrid path): replaces tevatron FaissFlatSearcher / faiss IndexFlatIP with
  * fp16 storage (src/search.py:232-237,254-270; call site search_queries src/search.py:55-63).
- * p_fp16 / q_fp16 are row-major IEEE fp16 matrices ([n][h] / [nq][h], h a multiple of 16); scores are f32-accumulated
+ * p_fp16 / q_fp16 are row-major IEEE fp16 matrices ([n][h] / [nq][h], h a multiple of 32); scores are f32-accumulated
  * on MFMA. Outputs [nq][k]: row indices (0xFFFFFFFF padding), order-preserving u32 keys of the f32 scores
  * (key = bits ^ 0x80000000 for non-negative, ~bits for negative floats; 0 = padding) and the hit count. */
 typedef struct msr_dense msr_dense;

@@ -1861,16 +1861,23 @@ __device__ __forceinline__ uint32_t f32_to_key(float f) {  // monotone: a < b  <
     return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
 }
 
-// One workgroup = 4 waves = a 128 (queries) x 128 (docs) block; each wave owns 64 x 64 = 2 x 2 MFMA tiles and reads
-// its A/B fragments straight from the row-major fp16 matrices (lane (r, h) holds elements k0+8h .. k0+8h+7 of row r:
-// one 16-byte load). Q has Mpad rows, P has Npad rows (multiples of 128, zero padded), H is a multiple of 16.
+// One workgroup = 4 waves = a 128 (queries) x 128 (docs) block, each wave 64 x 64 = 2 x 2 MFMA tiles of 32 x 32.
+// K runs in steps of 32 through a double-buffered LDS stage: 128 rows x 32 halves per operand, row stride 80 B
+// (5 sixteen-byte slots: 5r mod 16 is a bijection, so the 16-lane groups of ds_read_b128 hit 16 distinct slots).
+// The next K-step's global loads (2 x 16 B per operand per thread) are in flight while the current step's 8 MFMAs run.
+// Fragment map of v_mfma_f32_32x32x16_f16: lane (r = l & 31, h = l >> 5) holds elements k = 8h .. 8h+7 of row r of A
+// and of column r of B (= row r of P). Q has Mpad rows, P has Npad rows (multiples of 128, zero padded), H % 32 == 0.
+constexpr int kGemmRowB = 80;                    // LDS row stride in bytes (64 B of data + 16 B pad)
+constexpr int kGemmTileB = 128 * kGemmRowB;      // one operand stage
+
 __global__ __launch_bounds__(256) void dense_scores(const _Float16* __restrict__ Q, const _Float16* __restrict__ P,
                                                     uint32_t* __restrict__ out, uint32_t M, uint32_t N, uint32_t H,
                                                     uint64_t ld) {
-    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __shared__ __attribute__((aligned(16))) uint8_t stage[2][2][kGemmTileB];  // [buffer][A|B]
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t r = lane & 31, h = lane >> 5;
-    const uint32_t q_base = blockIdx.x * 128 + (wave >> 1) * 64;
-    const uint32_t d_base = blockIdx.y * 128 + (wave & 1) * 64;
+    const uint32_t wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
+    const uint32_t q_blk = blockIdx.x * 128, d_blk = blockIdx.y * 128;
     float16v acc[2][2];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -1878,28 +1885,57 @@ __global__ __launch_bounds__(256) void dense_scores(const _Float16* __restrict__
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-    const _Float16* qa = Q + (uint64_t)(q_base + r) * H + 8 * h;
-    const _Float16* pb = P + (uint64_t)(d_base + r) * H + 8 * h;
-    const uint64_t step32 = (uint64_t)32 * H;
-    for (uint32_t k0 = 0; k0 < H; k0 += 16) {
-        const half8 a0 = *reinterpret_cast<const half8*>(qa + k0);
-        const half8 a1 = *reinterpret_cast<const half8*>(qa + step32 + k0);
-        const half8 b0 = *reinterpret_cast<const half8*>(pb + k0);
-        const half8 b1 = *reinterpret_cast<const half8*>(pb + step32 + k0);
-        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b0, acc[0][0], 0, 0, 0);
-        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b1, acc[0][1], 0, 0, 0);
-        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b0, acc[1][0], 0, 0, 0);
-        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b1, acc[1][1], 0, 0, 0);
+    // global -> LDS assignment: 512 sixteen-byte segments per operand stage, two per thread (rows s/4, segment s%4)
+    const uint32_t s0 = tid, s1 = tid + 256;
+    const _Float16* ga0 = Q + (uint64_t)(q_blk + s0 / 4) * H + (s0 % 4) * 8;
+    const _Float16* ga1 = Q + (uint64_t)(q_blk + s1 / 4) * H + (s1 % 4) * 8;
+    const _Float16* gb0 = P + (uint64_t)(d_blk + s0 / 4) * H + (s0 % 4) * 8;
+    const _Float16* gb1 = P + (uint64_t)(d_blk + s1 / 4) * H + (s1 % 4) * 8;
+    const uint32_t l0 = (s0 / 4) * kGemmRowB + (s0 % 4) * 16, l1 = (s1 / 4) * kGemmRowB + (s1 % 4) * 16;
+    uint4 ra0, ra1, rb0, rb1;
+    auto g_load = [&](uint32_t k0) {
+        ra0 = *reinterpret_cast<const uint4*>(ga0 + k0);
+        ra1 = *reinterpret_cast<const uint4*>(ga1 + k0);
+        rb0 = *reinterpret_cast<const uint4*>(gb0 + k0);
+        rb1 = *reinterpret_cast<const uint4*>(gb1 + k0);
+    };
+    auto l_store = [&](int buf) {
+        *reinterpret_cast<uint4*>(&stage[buf][0][l0]) = ra0;
+        *reinterpret_cast<uint4*>(&stage[buf][0][l1]) = ra1;
+        *reinterpret_cast<uint4*>(&stage[buf][1][l0]) = rb0;
+        *reinterpret_cast<uint4*>(&stage[buf][1][l1]) = rb1;
+    };
+    const uint32_t fa = (wm + r) * kGemmRowB + 16 * h, fb = (wn + r) * kGemmRowB + 16 * h;
+    g_load(0);
+    l_store(0);
+    __syncthreads();
+    const uint32_t KT = H / 32;
+    for (uint32_t kt = 0; kt < KT; ++kt) {
+        const int cur = (int)(kt & 1);
+        if (kt + 1 < KT) g_load((kt + 1) * 32);
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            const half8 a0 = *reinterpret_cast<const half8*>(&stage[cur][0][fa + 32 * kk]);
+            const half8 a1 = *reinterpret_cast<const half8*>(&stage[cur][0][fa + 32 * kGemmRowB + 32 * kk]);
+            const half8 b0 = *reinterpret_cast<const half8*>(&stage[cur][1][fb + 32 * kk]);
+            const half8 b1 = *reinterpret_cast<const half8*>(&stage[cur][1][fb + 32 * kGemmRowB + 32 * kk]);
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b1, acc[1][1], 0, 0, 0);
+        }
+        if (kt + 1 < KT) l_store(cur ^ 1);
+        __syncthreads();
     }
     // C/D map of the 32x32 shapes: column = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-            const uint32_t d = d_base + 32 * j + r;
+            const uint32_t d = d_blk + wn + 32 * j + r;
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
-                const uint32_t q = q_base + 32 * i + (e & 3) + 8 * (e >> 2) + 4 * h;
+                const uint32_t q = q_blk + wm + 32 * i + (e & 3) + 8 * (e >> 2) + 4 * h;
                 if (q < M) out[(uint64_t)q * ld + d] = d < N ? f32_to_key(acc[i][j][e]) : 0u;
             }
         }
@@ -1926,8 +1962,8 @@ int msr_dense_open(const uint16_t* p_fp16, uint64_t n, uint32_t h, int device, m
         return MSR_E_INVAL;
     }
     *out = nullptr;
-    if ((!p_fp16 && n) || h == 0 || h % 16 != 0 || n >= (1ull << 31)) {
-        set_error("msr_dense_open: need fp16 rows with a dimension that is a multiple of 16 (got n=%llu, h=%u)",
+    if ((!p_fp16 && n) || h == 0 || h % 32 != 0 || n >= (1ull << 31)) {
+        set_error("msr_dense_open: need fp16 rows with a dimension that is a multiple of 32 (got n=%llu, h=%u)",
                   (unsigned long long)n, h);
         return MSR_E_INVAL;
     }

@@ -30,7 +30,7 @@ def _as_fp16_rows(x, dim=None):
     if x.ndim != 2:
         raise ValueError("expected a [rows, dim] matrix")
     h = x.shape[1]
-    pad = (-h) % 16
+    pad = (-h) % 32  # the GEMM steps K by 32; zero columns do not change inner products
     if dim is not None and h != dim:
         raise ValueError(f"dimension mismatch: {h} vs {dim}")
     x16 = x.astype(np.float16)
