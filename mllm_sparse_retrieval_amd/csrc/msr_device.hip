@@ -69,10 +69,27 @@ __device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v) {
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
     return v;
 }
-__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = max(v, (uint32_t)__shfl_xor(v, o, 64));
+// Unsigned max across lanes with DPP (VALU cross-lane operands, no LDS round trip like ds_bpermute):
+// quad_perm [1,0,3,2] -> quad_perm [2,3,0,1] -> row_half_mirror -> row_mirror leave every lane of a 4 / 8 / 16-lane
+// group with the group's maximum; row_bcast:15 / row_bcast:31 then carry the row maxima into lane 63.
+template <int CTRL, int ROW_MASK = 0xF>
+__device__ __forceinline__ uint32_t dpp_umax(uint32_t v) {
+    const uint32_t o = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, 0xF, false);  // unwritten lanes: 0
+    return max(v, o);
+}
+template <int G>  // maximum of every aligned group of G = 1, 2, 4, 8 or 16 lanes, in all lanes of the group
+__device__ __forceinline__ uint32_t group_max_u32(uint32_t v) {
+    if (G >= 2) v = dpp_umax<0xB1>(v);
+    if (G >= 4) v = dpp_umax<0x4E>(v);
+    if (G >= 8) v = dpp_umax<0x141>(v);
+    if (G >= 16) v = dpp_umax<0x140>(v);
     return v;
+}
+__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
+    v = group_max_u32<16>(v);
+    v = dpp_umax<0x142, 0xA>(v);  // row_bcast:15 into rows 1 and 3
+    v = dpp_umax<0x143, 0xC>(v);  // row_bcast:31 into rows 2 and 3
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
 }
 __device__ __forceinline__ uint64_t wave_max_u64(uint64_t v) {
 #pragma unroll
@@ -186,9 +203,8 @@ __device__ __forceinline__ void tile_select(const uint4* a4, uint64_t* cand, uin
     //             64 group maxima with ballots (no further barrier);
     //   k >  64 : groups are single threads (NT maxima, NT/64 per lane of wave 0), one more barrier.
     constexpr int G = NT / 64;  // threads per group
-    uint32_t gm = mymax;
-#pragma unroll
-    for (int o = 1; o < G; o <<= 1) gm = max(gm, (uint32_t)__shfl_xor(gm, o, 64));
+    static_assert(G == 4 || G == 8 || G == 16, "group maxima use the 4/8/16-lane DPP reductions");
+    const uint32_t gm = group_max_u32<G>(mymax);
     if ((lane & (G - 1)) == 0) wmax[tid / G] = gm;
     if (k > 64) tmax[tid] = mymax;
     __syncthreads();
