@@ -85,6 +85,21 @@ __device__ __forceinline__ uint32_t group_max_u32(uint32_t v) {
     if (G >= 16) v = dpp_umax<0x140>(v);
     return v;
 }
+// Inclusive prefix sum over the 64 lanes with DPP: row_shr 1, 2, 4, 8 build the scan inside every 16-lane row, then
+// row_bcast:15 / row_bcast:31 add the totals of the preceding rows.
+template <int CTRL, int ROW_MASK = 0xF, int BANK_MASK = 0xF>
+__device__ __forceinline__ uint32_t dpp_add(uint32_t v) {
+    return v + (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, BANK_MASK, false);  // unwritten lanes add 0
+}
+__device__ __forceinline__ uint32_t wave_inclusive_scan_u32(uint32_t v) {
+    v = dpp_add<0x111>(v);             // row_shr:1
+    v = dpp_add<0x112>(v);             // row_shr:2
+    v = dpp_add<0x114, 0xF, 0xE>(v);   // row_shr:4
+    v = dpp_add<0x118, 0xF, 0xC>(v);   // row_shr:8
+    v = dpp_add<0x142, 0xA>(v);        // row_bcast:15 into rows 1 and 3
+    v = dpp_add<0x143, 0xC>(v);        // row_bcast:31 into rows 2 and 3
+    return v;
+}
 __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
     v = group_max_u32<16>(v);
     v = dpp_umax<0x142, 0xA>(v);  // row_bcast:15 into rows 1 and 3
@@ -481,12 +496,7 @@ __global__ __launch_bounds__(NT, MIN_WAVES) void score_tiles(const ScoreArgs a) 
                 seg_w[tid] = w;
                 nch = (s1 - s0 + kChunkVecs - 1) / kChunkVecs;
             }
-            uint32_t inc = nch;  // inclusive scan inside the wave
-#pragma unroll
-            for (int o = 1; o < 64; o <<= 1) {
-                uint32_t up = __shfl_up(inc, o, 64);
-                if (lane >= (uint32_t)o) inc += up;
-            }
+            const uint32_t inc = wave_inclusive_scan_u32(nch);
             if (lane == 63) wsum[wave] = inc;
             nch = inc - nch;  // exclusive within the wave
         }
