@@ -478,7 +478,8 @@ __global__ __launch_bounds__(NT, MIN_WAVES) void score_tiles(const ScoreArgs a) 
 
     for (uint32_t base = qb; base < qe; base += kQtBlock) {
         const uint32_t cnt = min((uint32_t)kQtBlock, qe - base);
-        __syncthreads();  // previous round's readers of seg_* are done; zeroing is visible
+        if (base != qb) __syncthreads();  // the previous round's readers of seg_* / pref are done (the accumulator
+                                          // init is ordered before the atomics by the two barriers below)
         stamp(0);  // zeroing (+ q_ptr fetch)
         // ---- stage the round's segments and an exclusive prefix sum of their chunk counts
         uint32_t nch = 0;
