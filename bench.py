@@ -401,6 +401,7 @@ def main():
     ap.add_argument("--c4-tile-docs", type=int, default=0)
     ap.add_argument("--dense-max", type=int, default=-1, help="index build option dense_max_terms (-1: library default)")
     ap.add_argument("--dense-density", type=float, default=-1.0, help="index build option dense_min_density")
+    ap.add_argument("--c4-timeout", type=float, default=900.0, help="watchdog for the 1 M-doc object at N > 1 (s)")
     ap.add_argument("--no-c4", action="store_true", help="skip the 1 M-doc extra object")
     ap.add_argument("--no-term-shards", action="store_true", help="skip the term-range sharded variant at N > 1")
     ap.add_argument("--only-c4", action="store_true", help="(profiling) run only the 1 M-doc workload")
@@ -434,15 +435,36 @@ def main():
         except Exception as e:
             out["c5_hybrid"] = {"error": f"{type(e).__name__}: {e}"}
             log(f"[bench] c5_hybrid failed: {out['c5_hybrid']['error']}")
+    hung = False
     if not args.no_c4 and not args.only_c5:
-        try:
-            c4 = run_c4(args, ranks, m, wlmod)
-        except Exception as e:  # the extra object must never take the headline line down
-            c4 = {"error": f"{type(e).__name__}: {e}"}
-            log(f"[bench r{ranks.rank}] c4_1m failed: {c4['error']}")
-        out["c4_1m"] = c4
+        # The extra object must never take the headline line down: exceptions are caught, and at N > 1 (RCCL paths that
+        # cannot be rehearsed on a 1-GPU box) a watchdog bounds the wait so that the JSON line is printed regardless.
+        box = {}
+
+        def work():
+            try:
+                box["c4"] = run_c4(args, ranks, m, wlmod)
+            except Exception as e:
+                box["c4"] = {"error": f"{type(e).__name__}: {e}"}
+                log(f"[bench r{ranks.rank}] c4_1m failed: {box['c4']['error']}")
+
+        if ranks.world > 1:
+            import threading
+
+            t = threading.Thread(target=work, daemon=True)
+            t.start()
+            t.join(args.c4_timeout)
+            if t.is_alive():
+                hung = True
+                box["c4"] = {"error": f"no completion within {args.c4_timeout:.0f}s (multi-rank exchange hung?)"}
+        else:
+            work()
+        out["c4_1m"] = box["c4"]
     if ranks.rank == 0:
         print(json.dumps(out), file=real_stdout, flush=True)
+    if hung:
+        real_stdout.flush()
+        os._exit(0)  # a native call is stuck: leave without joining it
     ranks.close()
 
 

@@ -442,3 +442,48 @@ def test_gpu_fusion_matches_host_fuse(m, tmp_path, n, alpha, remove):
                 assert abs(float(want[qid][got_ids[i][j]]) - float(score)) <= 2e-6
         if remove:
             assert qid not in got_ids[i]
+
+
+def test_randomised_configurations(m, tmp_path):
+    """Fuzz: random corpus shapes, vocabularies, weights (including the 65 535 maximum), tile sizes, dense-head
+    options, query shapes (OOV, zero weights, repeats) and k, each against the C oracle."""
+    rng = np.random.default_rng(20250418)
+    for case in range(24):
+        n_docs = int(rng.integers(1, 20000))
+        n_terms = int(rng.integers(1, 400))
+        nnz = int(rng.integers(1, min(n_terms, 40) + 1))
+        tile = int(rng.choice([4096, 8192, 12288, 16384, 32768]))
+        dp = np.arange(0, n_docs * nnz + 1, nnz, dtype=np.uint64)
+        if n_docs * nnz < 200000:
+            dt = np.concatenate([rng.choice(n_terms, nnz, replace=False) for _ in range(n_docs)]).astype(np.uint32)
+        else:
+            dt = rng.integers(0, n_terms, n_docs * nnz).astype(np.uint32)
+        hi = int(rng.choice([3, 50, 400, 65535]))
+        dw = rng.integers(0, hi + 1, n_docs * nnz).astype(np.uint32)
+        # repeated terms inside a row add up: keep the sum within the 16-bit weight range
+        if hi == 65535:
+            dw = np.minimum(dw, 65535 // nnz).astype(np.uint32)
+        nq = int(rng.integers(1, 60))
+        qn = int(rng.integers(1, 30))
+        qp = np.arange(0, nq * qn + 1, qn, dtype=np.int64)
+        qt = rng.integers(-1, n_terms, nq * qn).astype(np.int32)
+        qw = rng.integers(-1, 40, nq * qn).astype(np.int32)
+        m.set_build_option("dense_max_terms", int(rng.choice([0, 3, 16, 32])))
+        m.set_build_option("dense_min_density", float(rng.choice([0.01, 0.2, 0.4, 0.9])))
+        try:
+            path = m.build_index_from_csr(str(tmp_path / f"z{case}.idx"), dp, dt, dw, n_terms, tile_docs=tile)
+        finally:
+            m.set_build_option("dense_max_terms", 16)
+            m.set_build_option("dense_min_density", 0.4)
+        oix, _ = helpers.taat_oracle((dp, dt, dw), n_terms)
+        with m.SparseIndex(path, device=0) as ix:
+            for k in {1, int(rng.integers(2, 200)), 1024}:
+                for drop in (True, False):
+                    try:
+                        want = oix.search(qp, qt, qw, k, drop_df_eq_n=drop, threads=4)
+                    except OverflowError:
+                        with pytest.raises(Exception, match="OVERFLOW"):
+                            ix.search_csr(qp, qt, qw, k, drop_df_eq_n=drop)
+                        continue
+                    helpers.assert_same_results(ix.search_csr(qp, qt, qw, k, drop_df_eq_n=drop), want, k)
+        os.remove(path)
