@@ -180,6 +180,13 @@ int msr_hybrid_search(msr_index* ix, msr_dense* dx, const int64_t* q_ptr, const 
                       const uint32_t* row2ord, const int32_t* self_ord, uint32_t* out_ord, float* out_score, int32_t* out_n,
                       float ms[4]);
 
+/* ---- encode-side sparsifier: log(1 + relu(logit)) -> top-k -> rint(x * 100) (src/model.py:104, src/encode.py:69-75).
+ * logits: row-major [rows][vocab], f32 (is_f16 = 0) or IEEE fp16 (is_f16 = 1). fp16_math = 1 rounds 1 + relu and the
+ * log to half like a model running in fp16. Outputs [rows][k]: vocabulary ids (ties: lower id first), the selected
+ * values v and the integer weights rint(v * 100). */
+int msr_sparsify(const void* logits, int is_f16, int fp16_math, int rows, uint32_t vocab, int k, int device,
+                 uint32_t* out_idx, float* out_val, int32_t* out_weight);
+
 /* ---- synthetic encode step (SURVEY.md §8d generator; stands in for src/encode.py when no MLLM is present) ----
  * Fills a doc-major CSR of n vectors with `nnz` distinct terms each, drawn without replacement from
  * p(r) ~ r^-zipf_s over n_terms, weights max(1, rint(100*ln(1+x))), x ~ LogNormal(0.5, 0.6), clipped to [1,400].

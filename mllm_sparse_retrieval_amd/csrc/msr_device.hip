@@ -2383,3 +2383,128 @@ int msr_hybrid_search(msr_index* ix, msr_dense* dx, const int64_t* q_ptr, const 
 }
 
 }  // extern "C"
+
+// ================================================================================================ encode-side sparsifier
+// The step immediately upstream of the index / the query encoder: per row of next-token logits
+//     v = log(1 + relu(logit))                       src/model.py:104
+//     top-k of v (k = 128 or --sparse_length)        src/encode.py:69-72
+//     weight = rint(v * 100) as int                  src/encode.py:75
+// One elementwise kernel turns the logits into order-preserving keys of v in the select_tiles layout; selection and
+// the tile merge are the kernels of the search path. fp16_math = 1 reproduces a model that runs in fp16 (1 + relu and
+// the log are rounded to half before the f32 multiplication by 100), 0 keeps f32 throughout.
+namespace msr {
+
+__global__ __launch_bounds__(256) void sparsify_keys(const void* __restrict__ logits, int is_f16, int fp16_math,
+                                                     uint32_t* __restrict__ out, uint32_t V, uint64_t ld) {
+    const uint32_t row = blockIdx.y;
+    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < V; i += gridDim.x * 256) {
+        float x = is_f16 ? (float)reinterpret_cast<const _Float16*>(logits)[(uint64_t)row * V + i]
+                         : reinterpret_cast<const float*>(logits)[(uint64_t)row * V + i];
+        float v;
+        if (fp16_math) {
+            const _Float16 y = (_Float16)((_Float16)1.0f + (_Float16)fmaxf(x, 0.f));  // half add, round to nearest even
+            v = (float)(_Float16)logf((float)y);
+        } else {
+            v = logf(1.0f + fmaxf(x, 0.f));
+        }
+        out[(uint64_t)row * ld + i] = f32_to_key(v);
+    }
+}
+
+}  // namespace msr
+
+extern "C" int msr_sparsify(const void* logits, int is_f16, int fp16_math, int rows, uint32_t vocab, int k, int device,
+                            uint32_t* out_idx, float* out_val, int32_t* out_weight) {
+    if (!logits || rows < 0 || vocab == 0 || !out_idx || !out_val || !out_weight) {
+        set_error("msr_sparsify: bad argument");
+        return MSR_E_INVAL;
+    }
+    if (k < 1 || k > MSR_KMAX) {
+        set_error("k must be in [1, %d] (got %d)", MSR_KMAX, k);
+        return MSR_E_RANGE;
+    }
+    int n_dev = 0;
+    if (device < 0 || hipGetDeviceCount(&n_dev) != hipSuccess || device >= n_dev) {
+        set_error("no usable HIP device %d; there is no CPU sparsifier path", device);
+        return MSR_E_NODEVICE;
+    }
+    if (rows == 0) return MSR_OK;
+    HIP_TRY(hipSetDevice(device));
+    const uint32_t tile = vocab <= 4096 ? 4096 : 8192;
+    const uint32_t n_tiles = (vocab + tile - 1) / tile;
+    const uint64_t ld = (uint64_t)n_tiles * tile;
+    const size_t in_bytes = (size_t)rows * vocab * (is_f16 ? 2 : 4);
+    void* d_in = nullptr;
+    uint32_t *d_keys = nullptr, *d_ord = nullptr, *d_su = nullptr;
+    uint64_t* d_part = nullptr;
+    float* d_sf = nullptr;
+    int32_t* d_n = nullptr;
+    hipStream_t st = nullptr;
+    const size_t per = (size_t)rows * k;
+    int rc = MSR_OK;
+    bool ok = hipStreamCreateWithFlags(&st, hipStreamNonBlocking) == hipSuccess && hipMalloc(&d_in, in_bytes) == hipSuccess &&
+              hipMalloc(&d_keys, (size_t)rows * ld * 4) == hipSuccess && hipMalloc(&d_part, (size_t)n_tiles * per * 8) == hipSuccess &&
+              hipMalloc(&d_ord, per * 4) == hipSuccess && hipMalloc(&d_su, per * 4) == hipSuccess &&
+              hipMalloc(&d_sf, per * 4) == hipSuccess && hipMalloc(&d_n, (size_t)rows * 4) == hipSuccess &&
+              hipMemcpyAsync(d_in, logits, in_bytes, hipMemcpyHostToDevice, st) == hipSuccess &&
+              hipMemsetAsync(d_keys, 0, (size_t)rows * ld * 4, st) == hipSuccess;
+    if (!ok) {
+        set_error("device setup failed in msr_sparsify");
+        rc = MSR_E_NOMEM;
+    }
+    if (rc == MSR_OK) {
+        hipLaunchKernelGGL(sparsify_keys, dim3(std::min<uint32_t>((vocab + 255) / 256, 1024), (uint32_t)rows), dim3(256), 0, st,
+                           d_in, is_f16, fp16_math, d_keys, vocab, ld);
+        SelectArgs se;
+        se.src = d_keys;
+        se.part = d_part;
+        se.n_docs = vocab;
+        se.n_tiles = n_tiles;
+        se.tpr = n_tiles;
+        se.rank = 0;
+        se.nq = (uint32_t)rows;
+        se.q0 = 0;
+        se.qn = (uint32_t)rows;
+        se.k = (uint32_t)k;
+        rc = launch_select(st, tile, se);
+    }
+    if (rc == MSR_OK) {
+        MergeArgs ma;
+        ma.lists = d_part;
+        ma.list_stride = per;
+        ma.n_lists = n_tiles;
+        ma.nq = (uint32_t)rows;
+        ma.k = (uint32_t)k;
+        ma.out_keys = nullptr;
+        ma.out_ord = d_ord;
+        ma.out_score_u32 = d_su;
+        ma.out_score = d_sf;
+        ma.out_n = d_n;
+        rc = launch_merge(st, ma);
+    }
+    std::vector<uint32_t> keys(per);
+    if (rc == MSR_OK) {
+        bool c = hipMemcpyAsync(out_idx, d_ord, per * 4, hipMemcpyDeviceToHost, st) == hipSuccess &&
+                 hipMemcpyAsync(keys.data(), d_su, per * 4, hipMemcpyDeviceToHost, st) == hipSuccess &&
+                 hipStreamSynchronize(st) == hipSuccess;
+        if (!c) {
+            set_error("sparsifier kernels or download failed: %s", hipGetErrorString(hipGetLastError()));
+            rc = MSR_E_HIP;
+        }
+    }
+    if (rc == MSR_OK)
+        for (size_t i = 0; i < per; ++i) {
+            const uint32_t key = keys[i];
+            const uint32_t bits = (key & 0x80000000u) ? (key & 0x7FFFFFFFu) : ~key;
+            float v;
+            memcpy(&v, &bits, 4);
+            if (!key) v = 0.f;
+            out_val[i] = v;
+            out_weight[i] = (int32_t)nearbyintf(v * 100.0f);  // np.rint(v * 100).astype(int), src/encode.py:75
+        }
+    void* ptrs[] = {d_in, d_keys, d_part, d_ord, d_su, d_sf, d_n};
+    for (void* p : ptrs)
+        if (p) (void)hipFree(p);
+    if (st) (void)hipStreamDestroy(st);
+    return rc;
+}

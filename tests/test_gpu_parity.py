@@ -487,3 +487,34 @@ def test_randomised_configurations(m, tmp_path):
                         continue
                     helpers.assert_same_results(ix.search_csr(qp, qt, qw, k, drop_df_eq_n=drop), want, k)
         os.remove(path)
+
+
+@pytest.mark.parametrize("dtype,vocab,k", [("float32", 32064, 128), ("float16", 128256, 128), ("float16", 3000, 256)])
+def test_sparsifier_against_torch(m, dtype, vocab, k):
+    """log(1 + relu) -> topk -> rint(x * 100) against plain PyTorch on the CPU (src/model.py:104, src/encode.py:69-75).
+    Floating point: values within 1e-6 (f32) / equal after the fp16 rounding; integer weights equal except where
+    v * 100 sits within float noise of a .5 boundary (f32 only); ids equal except inside exact value ties."""
+    import torch
+
+    from mllm_sparse_retrieval_amd.sparsify import sparsify_logits
+
+    rng = np.random.default_rng(vocab)
+    x = (rng.standard_normal((6, vocab)) * 4).astype(dtype)
+    ids, vals, w = sparsify_logits(x, k)
+    t = torch.from_numpy(x)
+    ref = torch.log(1 + torch.relu(t))
+    tv, ti = ref.topk(k, dim=-1)
+    tv32 = tv.float().numpy()
+    want_w = np.rint(tv32 * 100).astype(int)
+    tol = 2e-6 if dtype == "float32" else 0.0
+    assert np.abs(vals - tv32).max() <= tol + (1e-3 if dtype == "float16" else 0)  # torch's half log may differ by 1 ulp
+    bad = w != want_w
+    assert bad.mean() <= (0.002 if dtype == "float32" else 0.02)
+    assert np.abs(w - want_w).max() <= 1
+    # ids: same SET per row once exact ties at the k-th value are set aside
+    for r in range(6):
+        kth = tv32[r, -1]
+        a = {int(i) for i, v in zip(ids[r], vals[r]) if v > kth + 1e-3}
+        b = {int(i) for i, v in zip(ti[r].numpy(), tv32[r]) if v > kth + 1e-3}
+        assert a == b
+    assert (np.diff(vals, axis=1) <= 0).all()
