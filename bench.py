@@ -226,7 +226,7 @@ def run_headline(args, ranks, m, wlmod):
             out["cpu_baseline"] = cb
             out["parity"] = par
             out["speedup_vs_cpu"] = round(out["value"] / cb["value"], 1)
-        if ranks.world == 1:
+        if ranks.world == 1 and not args.no_cpu:  # (--no-cpu = profiling runs: only the timed launches)
             # PCIe-inclusive figures (never `value`): host CSR in -> host results out through msr_search_csr, and the
             # reference's own call shape of 4 queries per batch_search call (scripts/search_sparse.sh:16)
             ix.search_csr(qp, qt, qw, wl.k)
