@@ -1250,8 +1250,15 @@ static int batch_search_local(msr_batch* b, int k, bool final_arrays) {
             sa.stamps = b->d_stamps;
         }
     }
-    int rc = launch_score(d->stream, h->tile_docs, ix->shard_ntiles, sa);
-    if (rc != MSR_OK) return rc;
+    // one launch holds at most 2^31-1 workgroups (tiles x queries): larger batches go in query ranges
+    int rc = MSR_OK;
+    const uint32_t q_step = ix->shard_ntiles ? std::max<uint32_t>(0x7FFFFFFFu / ix->shard_ntiles, 1u) : (uint32_t)b->nq;
+    for (uint32_t q0 = 0; q0 < (uint32_t)b->nq; q0 += q_step) {
+        sa.q0 = q0;
+        sa.qn = std::min<uint32_t>(q_step, (uint32_t)b->nq - q0);
+        rc = launch_score(d->stream, h->tile_docs, ix->shard_ntiles, sa);
+        if (rc != MSR_OK) return rc;
+    }
     HIP_TRY(hipEventRecord(b->ev1, d->stream));
     MergeArgs ma;
     ma.lists = b->d_part;

@@ -152,7 +152,16 @@ class SparseIndex:
         check(lib().msr_docid_str(self._h, int(ordinal), C.byref(s)))
         return s.value.decode("utf-8", "surrogateescape")
 
+    def docid_table(self):
+        """All external doc ids by ordinal as a numpy object array (built once; one C call per doc)."""
+        if getattr(self, "_docid_table", None) is None:
+            self._docid_table = np.array([self.docid(o) for o in range(self.n_docs)], dtype=object)
+        return self._docid_table
+
     def docids(self, ordinals):
+        ordinals = np.asarray(ordinals, dtype=np.int64)
+        if self.n_docs <= 4_000_000 and (ordinals.size > 64 or getattr(self, "_docid_table", None) is not None):
+            return self.docid_table()[ordinals].tolist()
         return [self.docid(o) for o in ordinals]
 
     # ---- search

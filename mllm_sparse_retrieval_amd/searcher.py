@@ -84,8 +84,11 @@ class LuceneImpactSearcher:
             ws = np.where((df > 0) & (idf > self.min_idf), ws, 0).astype(np.int32)
         ords, scores, _, n = self.index.search_csr(q_ptr, term_ids, ws, k, drop_df_eq_n=self.min_idf >= 0)
         out = {}
+        table = self.index.docid_table() if len(qids) * k > 64 else None
+        score_rows = scores.tolist()
         for i, qid in enumerate(qids):  # duplicate qids collapse, like the qid-keyed map pyserini returns
             cnt = int(n[i])
-            ids = self.index.docids(ords[i, :cnt])
-            out[qid] = [Hit(ids[j], float(scores[i, j])) for j in range(cnt)]
+            ids = table[ords[i, :cnt]].tolist() if table is not None else self.index.docids(ords[i, :cnt])
+            row = score_rows[i]
+            out[qid] = [Hit(ids[j], row[j]) for j in range(cnt)]
         return out
