@@ -1,0 +1,141 @@
+// Shared by the two HIP translation units (msr_device.hip, msr_hybrid.hip): device-side state of an index, kernel
+// argument blocks, the resident query batch, and the few host functions that cross the unit boundary.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+
+#include <algorithm>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "msr_internal.h"
+
+namespace msr {
+
+#define HIP_TRY(expr)                                                                          \
+    do {                                                                                       \
+        hipError_t _e = (expr);                                                                \
+        if (_e != hipSuccess) {                                                                \
+            set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+            return MSR_E_HIP;                                                                  \
+        }                                                                                      \
+    } while (0)
+
+// ------------------------------------------------------------------------------------------------ constants
+constexpr int kQtBlock = 256;    // query terms staged in LDS per round
+constexpr int kCandCap = 1024;   // candidate keys per workgroup (>= MSR_KMAX)
+constexpr int kChunkVecs = 64;   // one chunk = one wave-wide uint4 load = 256 postings = 1 KiB
+static_assert(kCandCap >= MSR_KMAX, "candidate buffer must hold k keys");
+
+struct DeviceIndex {
+    int device = -1;
+    hipStream_t stream = nullptr;
+    uint32_t* d_seg_ptr = nullptr;   // [shard_ntiles][n_terms+1] absolute vec index
+    uint32_t* d_postings = nullptr;  // the shard's vecs; vec v of the index lives at d_postings + (v - vec_base)*4
+    uint32_t* d_dense = nullptr;     // [shard_ntiles][n_pairs][tile_docs] dense head of the shard's tiles
+    uint32_t n_pairs = 0;
+    uint32_t vec_base = 0;
+    uint64_t shard_vecs = 0;
+    std::vector<uint32_t> df_shard;  // postings of each term inside this shard (for algorithmic bytes)
+    bool df_shard_ready = false;
+    // exchange
+    ncclComm_t comm = nullptr;
+    int n_ranks = 1;
+    int rank = 0;
+};
+
+// ------------------------------------------------------------------------------------------------ kernel arguments
+struct ScoreArgs {
+    const uint32_t* seg_ptr;   // [ntiles][n_terms+1]
+    const uint32_t* postings;  // shard base
+    const uint32_t* q_ptr;     // [nq+1]
+    const uint32_t* q_term;
+    const uint32_t* q_w;
+    const uint32_t* dense;     // [ntiles][n_pairs][TILE_DOCS] dense head (weights of term 2p+1 << 16 | term 2p)
+    const uint32_t* q_dense;   // [nq][n_pairs] packed query weights of the dense-head terms (0 = absent)
+    uint32_t n_pairs;
+    uint64_t* part;            // [ntiles][nq][k] keys
+    uint64_t n_docs;           // whole index
+    uint32_t vec_base;
+    uint32_t n_terms;
+    uint32_t tile0;            // first (global) tile of the shard
+    uint32_t nq;               // queries of the batch (row stride of `part`)
+    uint32_t q0;               // this launch scores queries [q0, q0 + qn)
+    uint32_t qn;
+    uint32_t k;
+    // term-sharded search (MODE 1): instead of selecting, the accumulator tile is written (or added) to
+    // dump[((g * qn + (q - q0)) * tpr + t) * TILE_DOCS + i] with g = tile / tpr, t = tile % tpr  — the layout whose
+    // G equal chunks are the doc ranges that ncclReduceScatter hands to the G ranks
+    uint32_t* dump;
+    uint32_t tpr;              // tiles per rank = ceil(n_tiles / G)
+    uint32_t dump_add;         // 1: dump[...] += tile (single-GPU emulation of the reduction), 0: store
+    uint32_t dbg;              // MSR_DEBUG_FLAGS (timing ablations only; results are wrong when bits 0-2 are set)
+    unsigned long long* stamps;  // [8] summed s_memtime deltas of wave 0 per phase (dbg bit 3), else null
+};
+
+struct SelectArgs {
+    const uint32_t* src;
+    uint64_t* part;   // [tpr][nq][k]
+    uint64_t n_docs;
+    uint32_t n_tiles; // tiles of the whole index
+    uint32_t tpr;
+    uint32_t rank;
+    uint32_t nq, q0, qn, k;
+};
+
+struct MergeArgs {
+    const uint64_t* lists;   // key(list, q, j) = lists[list*list_stride + q*k + j]; 0 = empty slot
+    uint64_t list_stride;
+    uint32_t n_lists;
+    uint32_t nq;
+    uint32_t k;
+    uint64_t* out_keys;      // [nq][k] (may be null)
+    uint32_t* out_ord;       // [nq][k] (may be null)
+    uint32_t* out_score_u32;
+    float* out_score;
+    int32_t* out_n;
+};
+
+// defined in msr_device.hip
+int launch_select(hipStream_t st, uint32_t tile_docs, const SelectArgs& a);
+int launch_merge(hipStream_t st, const MergeArgs& a);
+
+}  // namespace msr
+
+struct msr_batch {
+    msr_index* ix = nullptr;
+    int nq = 0;
+    int kmax = 0;
+    int last_k = 0;
+    uint64_t nnz = 0;             // kept query entries
+    uint64_t sum_df = 0;          // sum over kept entries of df_shard(term)
+    uint32_t* d_qptr = nullptr;
+    uint32_t* d_qterm = nullptr;
+    uint32_t* d_qw = nullptr;
+    uint32_t* d_qdense = nullptr; // [nq][n_pairs]
+    uint64_t* d_part = nullptr;   // [ntiles][nq][kmax]
+    uint64_t* d_keys = nullptr;   // [nq][kmax] local top-k keys
+    uint64_t* d_gather = nullptr; // [n_ranks][nq][kmax] (sharded search)
+    uint32_t* d_ord = nullptr;
+    uint32_t* d_su32 = nullptr;
+    float* d_sf32 = nullptr;
+    int32_t* d_n = nullptr;
+    unsigned long long* d_stamps = nullptr;  // diagnostic (MSR_DEBUG_FLAGS bit 3)
+    // term-sharded search
+    uint32_t* d_S = nullptr;      // [G][Qt][tpr*tile] partial accumulators of one query tile (reduce-scatter send buffer)
+    uint32_t* d_R = nullptr;      // [Qt][tpr*tile] summed accumulators of this rank's doc range
+    uint64_t* d_tpart = nullptr;  // [tpr][nq][kmax] per-tile keys of this rank's doc range
+    size_t S_elems = 0, R_elems = 0, tpart_elems = 0;
+    int term_shard = -1, term_nshards = 0;  // >= 0: the batch holds only the query terms of that term range
+    hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr;  // the current call's events (borrowed from `events`)
+    std::vector<hipEvent_t> events;  // 3 per recorded search call since the last timing reset
+    size_t calls = 0;                // recorded calls
+    bool timed = false;
+};
+
+// defined in msr_device.hip
+void batch_free(msr_batch* b);
+extern "C" int batch_search_local(msr_batch* b, int k, bool final_arrays);  // internal, not part of include/msr.h

@@ -1,0 +1,636 @@
+// Hybrid path and encode-side sparsifier: the dense fp16 MFMA scorer (dense_scores), the reference's min-max fusion on
+// the GPU (fuse_tiles), the log1p-relu top-k sparsifier (sparsify_keys), and their C-ABI entry points. Selection and
+// list merging reuse the search path's kernels (launch_select / launch_merge, msr_device.hip).
+#include "msr_select.hpp"
+
+using namespace msr;
+
+// ================================================================================================ dense (hybrid path)
+// Flat inner-product search over fp16 passage vectors: the dense half of the reference's hybrid search
+// (tevatron FaissFlatSearcher / faiss IndexFlatIP, fp16 storage on GPU: src/search.py:232-237,254-270; queries
+// normalised at src/search.py:342, corpus at src/encode.py:301). Scores C[q][d] = sum_k Q[q][k] * P[d][k] on MFMA
+// (v_mfma_f32_32x32x16_f16, f32 accumulate), written as order-preserving u32 keys into the accumulator layout of
+// select_tiles, so that top-`depth` selection and the tile merge are the SAME kernels as on the sparse path.
+namespace msr {
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef float float16v __attribute__((ext_vector_type(16)));
+
+
+// One workgroup = 4 waves = a 128 (queries) x 128 (docs) block, each wave 64 x 64 = 2 x 2 MFMA tiles of 32 x 32.
+// K runs in steps of 32 through a double-buffered LDS stage: 128 rows x 32 halves per operand, row stride 80 B
+// (5 sixteen-byte slots: 5r mod 16 is a bijection, so the 16-lane groups of ds_read_b128 hit 16 distinct slots).
+// The next K-step's global loads (2 x 16 B per operand per thread) are in flight while the current step's 8 MFMAs run.
+// Fragment map of v_mfma_f32_32x32x16_f16: lane (r = l & 31, h = l >> 5) holds elements k = 8h .. 8h+7 of row r of A
+// and of column r of B (= row r of P). Q has Mpad rows, P has Npad rows (multiples of 128, zero padded), H % 32 == 0.
+constexpr int kGemmRowB = 80;                    // LDS row stride in bytes (64 B of data + 16 B pad)
+constexpr int kGemmTileB = 128 * kGemmRowB;      // one operand stage
+
+__global__ __launch_bounds__(256) void dense_scores(const _Float16* __restrict__ Q, const _Float16* __restrict__ P,
+                                                    uint32_t* __restrict__ out, uint32_t M, uint32_t N, uint32_t H,
+                                                    uint64_t ld) {
+    __shared__ __attribute__((aligned(16))) uint8_t stage[2][2][kGemmTileB];  // [buffer][A|B]
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t r = lane & 31, h = lane >> 5;
+    const uint32_t wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
+    const uint32_t q_blk = blockIdx.x * 128, d_blk = blockIdx.y * 128;
+    float16v acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+    // global -> LDS assignment: 512 sixteen-byte segments per operand stage, two per thread (rows s/4, segment s%4)
+    const uint32_t s0 = tid, s1 = tid + 256;
+    const _Float16* ga0 = Q + (uint64_t)(q_blk + s0 / 4) * H + (s0 % 4) * 8;
+    const _Float16* ga1 = Q + (uint64_t)(q_blk + s1 / 4) * H + (s1 % 4) * 8;
+    const _Float16* gb0 = P + (uint64_t)(d_blk + s0 / 4) * H + (s0 % 4) * 8;
+    const _Float16* gb1 = P + (uint64_t)(d_blk + s1 / 4) * H + (s1 % 4) * 8;
+    const uint32_t l0 = (s0 / 4) * kGemmRowB + (s0 % 4) * 16, l1 = (s1 / 4) * kGemmRowB + (s1 % 4) * 16;
+    uint4 ra0, ra1, rb0, rb1;
+    auto g_load = [&](uint32_t k0) {
+        ra0 = *reinterpret_cast<const uint4*>(ga0 + k0);
+        ra1 = *reinterpret_cast<const uint4*>(ga1 + k0);
+        rb0 = *reinterpret_cast<const uint4*>(gb0 + k0);
+        rb1 = *reinterpret_cast<const uint4*>(gb1 + k0);
+    };
+    auto l_store = [&](int buf) {
+        *reinterpret_cast<uint4*>(&stage[buf][0][l0]) = ra0;
+        *reinterpret_cast<uint4*>(&stage[buf][0][l1]) = ra1;
+        *reinterpret_cast<uint4*>(&stage[buf][1][l0]) = rb0;
+        *reinterpret_cast<uint4*>(&stage[buf][1][l1]) = rb1;
+    };
+    const uint32_t fa = (wm + r) * kGemmRowB + 16 * h, fb = (wn + r) * kGemmRowB + 16 * h;
+    g_load(0);
+    l_store(0);
+    __syncthreads();
+    const uint32_t KT = H / 32;
+    for (uint32_t kt = 0; kt < KT; ++kt) {
+        const int cur = (int)(kt & 1);
+        if (kt + 1 < KT) g_load((kt + 1) * 32);
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            const half8 a0 = *reinterpret_cast<const half8*>(&stage[cur][0][fa + 32 * kk]);
+            const half8 a1 = *reinterpret_cast<const half8*>(&stage[cur][0][fa + 32 * kGemmRowB + 32 * kk]);
+            const half8 b0 = *reinterpret_cast<const half8*>(&stage[cur][1][fb + 32 * kk]);
+            const half8 b1 = *reinterpret_cast<const half8*>(&stage[cur][1][fb + 32 * kGemmRowB + 32 * kk]);
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b1, acc[1][1], 0, 0, 0);
+        }
+        if (kt + 1 < KT) l_store(cur ^ 1);
+        __syncthreads();
+    }
+    // C/D map of the 32x32 shapes: column = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const uint32_t d = d_blk + wn + 32 * j + r;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const uint32_t q = q_blk + wm + 32 * i + (e & 3) + 8 * (e >> 2) + 4 * h;
+                if (q < M) out[(uint64_t)q * ld + d] = d < N ? f32_to_key(acc[i][j][e]) : 0u;
+            }
+        }
+}
+
+}  // namespace msr
+
+struct msr_dense {
+    int device = -1;
+    hipStream_t stream = nullptr;
+    _Float16* d_P = nullptr;  // [n_pad][h]
+    uint64_t n = 0;
+    uint64_t n_pad = 0;       // multiple of 128 and of tile_docs
+    uint32_t h = 0;
+    uint32_t tile_docs = 0;
+    uint32_t n_tiles = 0;
+};
+
+extern "C" {
+
+int msr_dense_open(const uint16_t* p_fp16, uint64_t n, uint32_t h, int device, msr_dense** out) {
+    if (!out) {
+        set_error("msr_dense_open: null output");
+        return MSR_E_INVAL;
+    }
+    *out = nullptr;
+    if ((!p_fp16 && n) || h == 0 || h % 32 != 0 || n >= (1ull << 31)) {
+        set_error("msr_dense_open: need fp16 rows with a dimension that is a multiple of 32 (got n=%llu, h=%u)",
+                  (unsigned long long)n, h);
+        return MSR_E_INVAL;
+    }
+    int n_dev = 0;
+    if (device < 0 || hipGetDeviceCount(&n_dev) != hipSuccess || device >= n_dev) {
+        set_error("no usable HIP device %d; there is no CPU dense search path", device);
+        return MSR_E_NODEVICE;
+    }
+    msr_dense* dx = new (std::nothrow) msr_dense;
+    if (!dx) {
+        set_error("out of host memory");
+        return MSR_E_NOMEM;
+    }
+    dx->device = device;
+    dx->n = n;
+    dx->h = h;
+    dx->tile_docs = n <= 4096 ? 4096 : 8192;
+    dx->n_tiles = (uint32_t)std::max<uint64_t>((n + dx->tile_docs - 1) / dx->tile_docs, 1);
+    dx->n_pad = (uint64_t)dx->n_tiles * dx->tile_docs;
+    const size_t bytes = (size_t)dx->n_pad * h * 2;
+    if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&dx->stream, hipStreamNonBlocking) != hipSuccess ||
+        hipMalloc(&dx->d_P, bytes) != hipSuccess || hipMemset(dx->d_P, 0, bytes) != hipSuccess ||
+        (n && hipMemcpy(dx->d_P, p_fp16, (size_t)n * h * 2, hipMemcpyHostToDevice) != hipSuccess)) {
+        set_error("device setup of the dense index failed (%zu bytes)", bytes);
+        if (dx->d_P) (void)hipFree(dx->d_P);
+        if (dx->stream) (void)hipStreamDestroy(dx->stream);
+        delete dx;
+        return MSR_E_HIP;
+    }
+    *out = dx;
+    return MSR_OK;
+}
+
+void msr_dense_close(msr_dense* dx) {
+    if (!dx) return;
+    (void)hipSetDevice(dx->device);
+    if (dx->d_P) (void)hipFree(dx->d_P);
+    if (dx->stream) (void)hipStreamDestroy(dx->stream);
+    delete dx;
+}
+
+// to_device = true: out_* are DEVICE buffers ([nq][k] / [nq]) filled on dx->stream (hybrid path); else host buffers.
+static int dense_search_impl(msr_dense* dx, const uint16_t* q_fp16, int nq, int k, uint32_t* out_idx, uint32_t* out_key,
+                             int32_t* out_n, float* gemm_ms, float* select_ms, bool to_device) {
+    if (!dx || nq < 0 || (nq && !q_fp16) || !out_idx || !out_key || !out_n) {
+        set_error("msr_dense_search: bad argument");
+        return MSR_E_INVAL;
+    }
+    if (k < 1 || k > MSR_KMAX) {
+        set_error("k must be in [1, %d] (got %d)", MSR_KMAX, k);
+        return MSR_E_RANGE;
+    }
+    HIP_TRY(hipSetDevice(dx->device));
+    const uint32_t QT = 8192;  // queries per pass: scores buffer QT x n_pad u32
+    const uint32_t qt = (uint32_t)std::min<uint32_t>(QT, std::max(nq, 1));
+    const uint32_t qt_pad = (qt + 127) / 128 * 128;
+    _Float16* d_Q = nullptr;
+    uint32_t* d_S = nullptr;
+    uint64_t *d_part = nullptr;
+    uint32_t *d_ord = nullptr, *d_su = nullptr;
+    float* d_sf = nullptr;
+    int32_t* d_n = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr;
+    int rc = MSR_OK;
+    const size_t perq = std::max<size_t>((size_t)qt * k, 1);
+    bool ok = hipMalloc(&d_Q, (size_t)qt_pad * dx->h * 2) == hipSuccess &&
+              hipMalloc(&d_S, (size_t)qt_pad * dx->n_pad * 4) == hipSuccess &&
+              hipMalloc(&d_part, (size_t)dx->n_tiles * perq * 8) == hipSuccess && hipMalloc(&d_ord, perq * 4) == hipSuccess &&
+              hipMalloc(&d_su, perq * 4) == hipSuccess && hipMalloc(&d_sf, perq * 4) == hipSuccess &&
+              hipMalloc(&d_n, (size_t)qt * 4) == hipSuccess && hipEventCreate(&e0) == hipSuccess &&
+              hipEventCreate(&e1) == hipSuccess && hipEventCreate(&e2) == hipSuccess;
+    if (!ok) {
+        set_error("hipMalloc failed in msr_dense_search (%u queries per pass x %llu docs)", qt, (unsigned long long)dx->n_pad);
+        rc = MSR_E_NOMEM;
+    }
+    double t_gemm = 0, t_sel = 0;
+    for (int q0 = 0; q0 < nq && rc == MSR_OK; q0 += (int)qt) {
+        const uint32_t qn = (uint32_t)std::min<int>((int)qt, nq - q0);
+        const uint32_t qn_pad = (qn + 127) / 128 * 128;
+        bool c = hipMemsetAsync(d_Q, 0, (size_t)qn_pad * dx->h * 2, dx->stream) == hipSuccess &&
+                 hipMemcpyAsync(d_Q, q_fp16 + (size_t)q0 * dx->h, (size_t)qn * dx->h * 2, hipMemcpyHostToDevice,
+                                dx->stream) == hipSuccess &&
+                 hipEventRecord(e0, dx->stream) == hipSuccess;
+        if (!c) {
+            set_error("query upload failed in msr_dense_search");
+            rc = MSR_E_HIP;
+            break;
+        }
+        hipLaunchKernelGGL(dense_scores, dim3(qn_pad / 128, (uint32_t)(dx->n_pad / 128)), dim3(256), 0, dx->stream, d_Q,
+                           dx->d_P, d_S, qn, (uint32_t)dx->n, dx->h, dx->n_pad);
+        (void)hipEventRecord(e1, dx->stream);
+        SelectArgs se;
+        se.src = d_S;
+        se.part = d_part;
+        se.n_docs = dx->n;
+        se.n_tiles = dx->n_tiles;
+        se.tpr = dx->n_tiles;
+        se.rank = 0;
+        se.nq = qn;
+        se.q0 = 0;
+        se.qn = qn;
+        se.k = (uint32_t)k;
+        rc = launch_select(dx->stream, dx->tile_docs, se);
+        if (rc != MSR_OK) break;
+        MergeArgs ma;
+        ma.lists = d_part;
+        ma.list_stride = (uint64_t)qn * k;
+        ma.n_lists = dx->n_tiles;
+        ma.nq = qn;
+        ma.k = (uint32_t)k;
+        ma.out_keys = nullptr;
+        ma.out_ord = d_ord;
+        ma.out_score_u32 = d_su;
+        ma.out_score = d_sf;
+        ma.out_n = d_n;
+        rc = launch_merge(dx->stream, ma);
+        if (rc != MSR_OK) break;
+        (void)hipEventRecord(e2, dx->stream);
+        const hipMemcpyKind kind = to_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
+        c = hipMemcpyAsync(out_idx + (size_t)q0 * k, d_ord, (size_t)qn * k * 4, kind, dx->stream) == hipSuccess &&
+            hipMemcpyAsync(out_key + (size_t)q0 * k, d_su, (size_t)qn * k * 4, kind, dx->stream) == hipSuccess &&
+            hipMemcpyAsync(out_n + q0, d_n, (size_t)qn * 4, kind, dx->stream) == hipSuccess &&
+            hipStreamSynchronize(dx->stream) == hipSuccess;
+        if (!c) {
+            set_error("dense search kernels or result download failed: %s", hipGetErrorString(hipGetLastError()));
+            rc = MSR_E_HIP;
+            break;
+        }
+        float a = 0, b2 = 0;
+        (void)hipEventElapsedTime(&a, e0, e1);
+        (void)hipEventElapsedTime(&b2, e1, e2);
+        t_gemm += a;
+        t_sel += b2;
+    }
+    if (gemm_ms) *gemm_ms = (float)t_gemm;
+    if (select_ms) *select_ms = (float)t_sel;
+    void* ptrs[] = {d_Q, d_S, d_part, d_ord, d_su, d_sf, d_n};
+    for (void* p : ptrs)
+        if (p) (void)hipFree(p);
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    if (e2) (void)hipEventDestroy(e2);
+    return rc;
+}
+
+int msr_dense_search(msr_dense* dx, const uint16_t* q_fp16, int nq, int k, uint32_t* out_idx, uint32_t* out_key,
+                     int32_t* out_n, float* gemm_ms, float* select_ms) {
+    return dense_search_impl(dx, q_fp16, nq, k, out_idx, out_key, out_n, gemm_ms, select_ms, false);
+}
+
+}  // extern "C"
+
+// ================================================================================================ hybrid fusion
+// The reference's fuse() (src/hybrid.py:32-53) on the GPU: per query, over the union of the dense and the sparse
+// top-`depth` lists,  fused(doc) = w_dense * (d - min_d) / max(max_d - min_d, 1e-9)   [if the dense list holds doc]
+//                                + w_sparse * (s - min_s) / max(max_s - min_s, 1e-9)  [if the sparse list holds doc]
+// with min/max over each UNFILTERED list (get_run_dict, src/search.py:76-81) and the query's own doc skipped when
+// remove_query is set (src/search.py:72-74). Fused scores are built in an LDS accumulator tile over doc ordinals and
+// the best k are selected by the same tile_select as everywhere else. f32 arithmetic (the reference mixes f32 and
+// f64 depending on the numpy version): scores agree within the north star's 1e-5.
+namespace msr {
+
+struct FuseArgs {
+    const uint64_t* s_keys;   // [nq][depth] sparse keys (score<<32 | ~ordinal), best first, 0 padded
+    const uint32_t* d_idx;    // [nq][depth] dense row indices, best first
+    const uint32_t* d_key;    // [nq][depth] order-preserving keys of the dense f32 scores, 0 padded
+    const int32_t* d_n;       // [nq]
+    const uint32_t* row2ord;  // dense row -> sparse doc ordinal
+    const int32_t* self_ord;  // [nq] ordinal to skip (remove_query) or -1; may be null
+    uint64_t* part;           // [n_tiles][nq][k]
+    uint64_t n_docs;
+    uint32_t nq, depth, k;
+    float w_dense, w_sparse;
+};
+
+
+template <int TILE_DOCS, int NT, int CAND>
+__global__ __launch_bounds__(NT) void fuse_tiles(const FuseArgs a) {
+    using L = TileLds<TILE_DOCS, NT, CAND>;
+    __shared__ __attribute__((aligned(16))) uint8_t lds[L::kTotal];
+    __shared__ uint8_t member[TILE_DOCS];
+    __shared__ float mm[4];  // min_s, den_s, min_d, den_d
+    uint32_t* const acc = reinterpret_cast<uint32_t*>(lds);
+    float* const facc = reinterpret_cast<float*>(lds);
+    uint8_t* const un = lds + L::kAcc;
+    uint64_t* const cand = reinterpret_cast<uint64_t*>(un);
+    uint32_t* const tmax = reinterpret_cast<uint32_t*>(un + L::kUnion);
+    uint32_t* const wmax = tmax + NT;
+    SelectScratch& ss = *reinterpret_cast<SelectScratch*>(un + L::kUnion + L::kTmax);
+    const uint32_t tid = threadIdx.x;
+    const uint32_t tile = blockIdx.x / a.nq, q = blockIdx.x % a.nq;
+    const uint64_t doc0 = (uint64_t)tile * TILE_DOCS;
+    const uint32_t ndocs_tile = (uint32_t)min((uint64_t)TILE_DOCS, a.n_docs - doc0);
+    const int rounds = (int)((ndocs_tile + 4 * NT - 1) / (4 * NT));
+    const uint64_t* sk = a.s_keys + (uint64_t)q * a.depth;
+    const uint32_t* di = a.d_idx + (uint64_t)q * a.depth;
+    const uint32_t* dk = a.d_key + (uint64_t)q * a.depth;
+    const int32_t dn = a.d_n[q];
+    const uint32_t self = a.self_ord ? (uint32_t)a.self_ord[q] : 0xFFFFFFFFu;
+
+    for (int i = tid; i < rounds * 4 * NT; i += NT) {
+        facc[i] = 0.f;
+        member[i] = 0;
+    }
+    __shared__ uint32_t ns_sh;
+    if (tid < 64) ss.cnt[tid] = 0;
+    if (tid == 0) {
+        ss.n_cand = 0;
+        ss.tau0 = 1;
+        ss.smax = 0;
+        ns_sh = 0;
+    }
+    __syncthreads();
+    for (uint32_t j = tid; j < a.depth; j += NT)
+        if (sk[j]) atomicMax(&ns_sh, j + 1);  // sparse hit count = index after the last non-empty slot
+    __syncthreads();
+    if (tid == 0) {
+        // lists are best-first: max = first entry, min = last non-empty entry
+        const uint32_t ns = ns_sh;
+        const float smax = ns ? (float)(uint32_t)(sk[0] >> 32) : 0.f, smin = ns ? (float)(uint32_t)(sk[ns - 1] >> 32) : 0.f;
+        const float dmax = dn > 0 ? key_to_f32(dk[0]) : 0.f, dmin = dn > 0 ? key_to_f32(dk[dn - 1]) : 0.f;
+        mm[0] = smin;
+        mm[1] = fmaxf(smax - smin, 1e-9f);
+        mm[2] = dmin;
+        mm[3] = fmaxf(dmax - dmin, 1e-9f);
+    }
+    __syncthreads();
+    // dense pass first (the reference adds the dense term first), then the sparse pass; docs are unique per list
+    for (int j = tid; j < dn; j += NT) {
+        const uint32_t ord = a.row2ord[di[j]];
+        if (ord != self && ord >= doc0 && ord < doc0 + ndocs_tile) {
+            facc[ord - doc0] = a.w_dense * ((key_to_f32(dk[j]) - mm[2]) / mm[3]);
+            member[ord - doc0] = 1;
+        }
+    }
+    __syncthreads();
+    for (uint32_t j = tid; j < a.depth; j += NT) {
+        const uint64_t key = sk[j];
+        if (!key) continue;
+        const uint32_t ord = 0xFFFFFFFFu - (uint32_t)key;
+        if (ord != self && ord >= doc0 && ord < doc0 + ndocs_tile) {
+            facc[ord - doc0] += a.w_sparse * (((float)(uint32_t)(key >> 32) - mm[0]) / mm[1]);
+            member[ord - doc0] = 1;
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < rounds * 4 * NT; i += NT) acc[i] = member[i] ? f32_to_key(facc[i]) : 0u;
+    __syncthreads();
+    tile_select<TILE_DOCS, NT, CAND>(reinterpret_cast<const uint4*>(lds), cand, tmax, wmax, ss, rounds, doc0, (int)a.k,
+                                     a.part + ((uint64_t)tile * a.nq + q) * a.k, [](int) {});
+}
+
+}  // namespace msr
+
+extern "C" {
+
+int msr_hybrid_search(msr_index* ix, msr_dense* dx, const int64_t* q_ptr, const int32_t* q_term, const int32_t* q_w,
+                      const uint16_t* q_fp16, int nq, int depth, int k, float alpha, uint32_t flags,
+                      const uint32_t* row2ord, const int32_t* self_ord, uint32_t* out_ord, float* out_score, int32_t* out_n,
+                      float ms[4]) {
+    if (!ix || !dx || !row2ord || !out_ord || !out_score || !out_n || nq < 0) {
+        set_error("msr_hybrid_search: bad argument");
+        return MSR_E_INVAL;
+    }
+    if (!ix->dev) {
+        set_error("index handle has no HIP device bound; there is no CPU scoring path");
+        return MSR_E_NODEVICE;
+    }
+    if (ix->dev->device != dx->device) {
+        set_error("the sparse and the dense index live on different devices");
+        return MSR_E_INVAL;
+    }
+    if (depth < 1 || depth > MSR_KMAX || k < 1 || k > MSR_KMAX) {
+        set_error("depth and k must be in [1, %d]", MSR_KMAX);
+        return MSR_E_RANGE;
+    }
+    if (dx->n != ix->host.h->n_docs) {
+        set_error("the dense index holds %llu rows but the sparse index %llu docs", (unsigned long long)dx->n,
+                  (unsigned long long)ix->host.h->n_docs);
+        return MSR_E_INVAL;
+    }
+    DeviceIndex* d = ix->dev;
+    const IndexHeader* h = ix->host.h;
+    msr_batch* b = nullptr;
+    int rc = msr_batch_create(ix, q_ptr, q_term, q_w, nq, depth, flags, &b);
+    if (rc != MSR_OK) return rc;
+    uint32_t *d_didx = nullptr, *d_dkey = nullptr, *d_map = nullptr, *d_ord = nullptr, *d_su = nullptr;
+    int32_t *d_dn = nullptr, *d_self = nullptr, *d_n = nullptr;
+    float* d_sf = nullptr;
+    uint64_t* d_part = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    const uint32_t ftile = h->n_docs <= 4096 ? 4096 : 8192;
+    const uint32_t ftiles = (uint32_t)std::max<uint64_t>((h->n_docs + ftile - 1) / ftile, 1);
+    const size_t per = std::max<size_t>((size_t)nq * depth, 1), perk = std::max<size_t>((size_t)nq * k, 1);
+    bool ok = hipSetDevice(d->device) == hipSuccess && hipMalloc(&d_didx, per * 4) == hipSuccess &&
+              hipMalloc(&d_dkey, per * 4) == hipSuccess && hipMalloc(&d_dn, std::max<size_t>(nq, 1) * 4) == hipSuccess &&
+              hipMalloc(&d_map, std::max<size_t>(h->n_docs, 1) * 4) == hipSuccess &&
+              hipMalloc(&d_part, (size_t)ftiles * perk * 8) == hipSuccess && hipMalloc(&d_ord, perk * 4) == hipSuccess &&
+              hipMalloc(&d_su, perk * 4) == hipSuccess && hipMalloc(&d_sf, perk * 4) == hipSuccess &&
+              hipMalloc(&d_n, std::max<size_t>(nq, 1) * 4) == hipSuccess && hipEventCreate(&e0) == hipSuccess &&
+              hipEventCreate(&e1) == hipSuccess &&
+              hipMemcpy(d_map, row2ord, (size_t)h->n_docs * 4, hipMemcpyHostToDevice) == hipSuccess;
+    if (ok && self_ord)
+        ok = hipMalloc(&d_self, std::max<size_t>(nq, 1) * 4) == hipSuccess &&
+             hipMemcpy(d_self, self_ord, (size_t)nq * 4, hipMemcpyHostToDevice) == hipSuccess;
+    if (!ok) {
+        set_error("device allocation failed in msr_hybrid_search");
+        rc = MSR_E_NOMEM;
+    }
+    float t_gemm = 0, t_sel = 0, t_sparse = 0, t_merge = 0, t_fuse = 0;
+    if (rc == MSR_OK) rc = batch_search_local(b, depth, false);  // sparse top-depth keys -> b->d_keys
+    if (rc == MSR_OK) rc = dense_search_impl(dx, q_fp16, nq, depth, d_didx, d_dkey, d_dn, &t_gemm, &t_sel, true);
+    if (rc == MSR_OK) {
+        (void)hipEventRecord(e0, d->stream);
+        FuseArgs fa;
+        fa.s_keys = b->d_keys;
+        fa.d_idx = d_didx;
+        fa.d_key = d_dkey;
+        fa.d_n = d_dn;
+        fa.row2ord = d_map;
+        fa.self_ord = d_self;
+        fa.part = d_part;
+        fa.n_docs = h->n_docs;
+        fa.nq = (uint32_t)nq;
+        fa.depth = (uint32_t)depth;
+        fa.k = (uint32_t)k;
+        fa.w_dense = alpha;
+        fa.w_sparse = 1.0f - alpha;
+        if (nq) {
+            if (ftile == 4096)
+                hipLaunchKernelGGL((fuse_tiles<4096, 256, 1024>), dim3(ftiles * (uint32_t)nq), dim3(256), 0, d->stream, fa);
+            else
+                hipLaunchKernelGGL((fuse_tiles<8192, 512, 1024>), dim3(ftiles * (uint32_t)nq), dim3(512), 0, d->stream, fa);
+        }
+        MergeArgs ma;
+        ma.lists = d_part;
+        ma.list_stride = (uint64_t)nq * k;
+        ma.n_lists = ftiles;
+        ma.nq = (uint32_t)nq;
+        ma.k = (uint32_t)k;
+        ma.out_keys = nullptr;
+        ma.out_ord = d_ord;
+        ma.out_score_u32 = d_su;
+        ma.out_score = d_sf;
+        ma.out_n = d_n;
+        rc = launch_merge(d->stream, ma);
+        (void)hipEventRecord(e1, d->stream);
+    }
+    if (rc == MSR_OK && hipStreamSynchronize(d->stream) != hipSuccess) {
+        set_error("hybrid kernels failed: %s", hipGetErrorString(hipGetLastError()));
+        rc = MSR_E_HIP;
+    }
+    if (rc == MSR_OK) {
+        (void)msr_batch_kernel_ms(b, &t_sparse, &t_merge);
+        (void)hipEventElapsedTime(&t_fuse, e0, e1);
+        // out_score: the fused f32 score is carried as an order-preserving key in the u32 score slot
+        std::vector<uint32_t> keys((size_t)nq * k);
+        bool c = (!nq) || (hipMemcpy(out_ord, d_ord, (size_t)nq * k * 4, hipMemcpyDeviceToHost) == hipSuccess &&
+                           hipMemcpy(keys.data(), d_su, (size_t)nq * k * 4, hipMemcpyDeviceToHost) == hipSuccess &&
+                           hipMemcpy(out_n, d_n, (size_t)nq * 4, hipMemcpyDeviceToHost) == hipSuccess);
+        if (!c) {
+            set_error("download failed in msr_hybrid_search");
+            rc = MSR_E_HIP;
+        } else {
+            for (size_t i = 0; i < keys.size(); ++i) {
+                const uint32_t key = keys[i];
+                uint32_t bits = (key & 0x80000000u) ? (key & 0x7FFFFFFFu) : ~key;
+                float f;
+                memcpy(&f, &bits, 4);
+                out_score[i] = key ? f : 0.f;
+            }
+        }
+    }
+    if (ms) {
+        ms[0] = t_sparse + t_merge;
+        ms[1] = t_gemm;
+        ms[2] = t_sel;
+        ms[3] = t_fuse;
+    }
+    void* ptrs[] = {d_didx, d_dkey, d_dn, d_map, d_self, d_part, d_ord, d_su, d_sf, d_n};
+    for (void* p : ptrs)
+        if (p) (void)hipFree(p);
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    batch_free(b);
+    return rc;
+}
+
+}  // extern "C"
+
+// ================================================================================================ encode-side sparsifier
+// The step immediately upstream of the index / the query encoder: per row of next-token logits
+//     v = log(1 + relu(logit))                       src/model.py:104
+//     top-k of v (k = 128 or --sparse_length)        src/encode.py:69-72
+//     weight = rint(v * 100) as int                  src/encode.py:75
+// One elementwise kernel turns the logits into order-preserving keys of v in the select_tiles layout; selection and
+// the tile merge are the kernels of the search path. fp16_math = 1 reproduces a model that runs in fp16 (1 + relu and
+// the log are rounded to half before the f32 multiplication by 100), 0 keeps f32 throughout.
+namespace msr {
+
+__global__ __launch_bounds__(256) void sparsify_keys(const void* __restrict__ logits, int is_f16, int fp16_math,
+                                                     uint32_t* __restrict__ out, uint32_t V, uint64_t ld) {
+    const uint32_t row = blockIdx.y;
+    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < V; i += gridDim.x * 256) {
+        float x = is_f16 ? (float)reinterpret_cast<const _Float16*>(logits)[(uint64_t)row * V + i]
+                         : reinterpret_cast<const float*>(logits)[(uint64_t)row * V + i];
+        float v;
+        if (fp16_math) {
+            const _Float16 y = (_Float16)((_Float16)1.0f + (_Float16)fmaxf(x, 0.f));  // half add, round to nearest even
+            v = (float)(_Float16)logf((float)y);
+        } else {
+            v = logf(1.0f + fmaxf(x, 0.f));
+        }
+        out[(uint64_t)row * ld + i] = f32_to_key(v);
+    }
+}
+
+}  // namespace msr
+
+extern "C" int msr_sparsify(const void* logits, int is_f16, int fp16_math, int rows, uint32_t vocab, int k, int device,
+                            uint32_t* out_idx, float* out_val, int32_t* out_weight) {
+    if (!logits || rows < 0 || vocab == 0 || !out_idx || !out_val || !out_weight) {
+        set_error("msr_sparsify: bad argument");
+        return MSR_E_INVAL;
+    }
+    if (k < 1 || k > MSR_KMAX) {
+        set_error("k must be in [1, %d] (got %d)", MSR_KMAX, k);
+        return MSR_E_RANGE;
+    }
+    int n_dev = 0;
+    if (device < 0 || hipGetDeviceCount(&n_dev) != hipSuccess || device >= n_dev) {
+        set_error("no usable HIP device %d; there is no CPU sparsifier path", device);
+        return MSR_E_NODEVICE;
+    }
+    if (rows == 0) return MSR_OK;
+    HIP_TRY(hipSetDevice(device));
+    const uint32_t tile = vocab <= 4096 ? 4096 : 8192;
+    const uint32_t n_tiles = (vocab + tile - 1) / tile;
+    const uint64_t ld = (uint64_t)n_tiles * tile;
+    const size_t in_bytes = (size_t)rows * vocab * (is_f16 ? 2 : 4);
+    void* d_in = nullptr;
+    uint32_t *d_keys = nullptr, *d_ord = nullptr, *d_su = nullptr;
+    uint64_t* d_part = nullptr;
+    float* d_sf = nullptr;
+    int32_t* d_n = nullptr;
+    hipStream_t st = nullptr;
+    const size_t per = (size_t)rows * k;
+    int rc = MSR_OK;
+    bool ok = hipStreamCreateWithFlags(&st, hipStreamNonBlocking) == hipSuccess && hipMalloc(&d_in, in_bytes) == hipSuccess &&
+              hipMalloc(&d_keys, (size_t)rows * ld * 4) == hipSuccess && hipMalloc(&d_part, (size_t)n_tiles * per * 8) == hipSuccess &&
+              hipMalloc(&d_ord, per * 4) == hipSuccess && hipMalloc(&d_su, per * 4) == hipSuccess &&
+              hipMalloc(&d_sf, per * 4) == hipSuccess && hipMalloc(&d_n, (size_t)rows * 4) == hipSuccess &&
+              hipMemcpyAsync(d_in, logits, in_bytes, hipMemcpyHostToDevice, st) == hipSuccess &&
+              hipMemsetAsync(d_keys, 0, (size_t)rows * ld * 4, st) == hipSuccess;
+    if (!ok) {
+        set_error("device setup failed in msr_sparsify");
+        rc = MSR_E_NOMEM;
+    }
+    if (rc == MSR_OK) {
+        hipLaunchKernelGGL(sparsify_keys, dim3(std::min<uint32_t>((vocab + 255) / 256, 1024), (uint32_t)rows), dim3(256), 0, st,
+                           d_in, is_f16, fp16_math, d_keys, vocab, ld);
+        SelectArgs se;
+        se.src = d_keys;
+        se.part = d_part;
+        se.n_docs = vocab;
+        se.n_tiles = n_tiles;
+        se.tpr = n_tiles;
+        se.rank = 0;
+        se.nq = (uint32_t)rows;
+        se.q0 = 0;
+        se.qn = (uint32_t)rows;
+        se.k = (uint32_t)k;
+        rc = launch_select(st, tile, se);
+    }
+    if (rc == MSR_OK) {
+        MergeArgs ma;
+        ma.lists = d_part;
+        ma.list_stride = per;
+        ma.n_lists = n_tiles;
+        ma.nq = (uint32_t)rows;
+        ma.k = (uint32_t)k;
+        ma.out_keys = nullptr;
+        ma.out_ord = d_ord;
+        ma.out_score_u32 = d_su;
+        ma.out_score = d_sf;
+        ma.out_n = d_n;
+        rc = launch_merge(st, ma);
+    }
+    std::vector<uint32_t> keys(per);
+    if (rc == MSR_OK) {
+        bool c = hipMemcpyAsync(out_idx, d_ord, per * 4, hipMemcpyDeviceToHost, st) == hipSuccess &&
+                 hipMemcpyAsync(keys.data(), d_su, per * 4, hipMemcpyDeviceToHost, st) == hipSuccess &&
+                 hipStreamSynchronize(st) == hipSuccess;
+        if (!c) {
+            set_error("sparsifier kernels or download failed: %s", hipGetErrorString(hipGetLastError()));
+            rc = MSR_E_HIP;
+        }
+    }
+    if (rc == MSR_OK)
+        for (size_t i = 0; i < per; ++i) {
+            const uint32_t key = keys[i];
+            const uint32_t bits = (key & 0x80000000u) ? (key & 0x7FFFFFFFu) : ~key;
+            float v;
+            memcpy(&v, &bits, 4);
+            if (!key) v = 0.f;
+            out_val[i] = v;
+            out_weight[i] = (int32_t)nearbyintf(v * 100.0f);  // np.rint(v * 100).astype(int), src/encode.py:75
+        }
+    void* ptrs[] = {d_in, d_keys, d_part, d_ord, d_su, d_sf, d_n};
+    for (void* p : ptrs)
+        if (p) (void)hipFree(p);
+    if (st) (void)hipStreamDestroy(st);
+    return rc;
+}

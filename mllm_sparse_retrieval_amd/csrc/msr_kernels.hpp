@@ -1,0 +1,435 @@
+// The search-path kernels (included by msr_device.hip only). Roofline class: HBM; no MFMA — this is
+// gather + integer reduce.
+//
+// score_tiles<TILE_DOCS, NT, U, MIN_WAVES, CAND, DBG, MODE>   one workgroup per (doc tile, query)
+//     - TILE_DOCS u32 accumulators in LDS (32 KiB at the default 8192 docs: four workgroups = 32 waves per CU),
+//     - dense-head terms: doc-major rows scored by the accumulator's owner with v_dot2_u32_u16 (this is also the
+//       accumulator init),
+//     - the query's other (term, tile) segments are cut into 1-KiB chunks (64 lanes x 16 B = 256 postings); waves take
+//       chunks round-robin, resolve 64 chunks lane-parallel, then walk them with v_readlane broadcasts: one uint4 load
+//       and four ds_add_u32 per lane and chunk, two register banks in flight,
+//     - exact per-tile top-k (tile_select, msr_select.hpp).
+//     Workgroups are ordered tile-major, so the ~1000 workgroups in flight score the SAME tile for different queries
+//     and the tile's rows and hot segments are served from the XCDs' L2s, not from HBM.
+// select_tiles   top-k of an accumulator tile that already sits in HBM (term shards, dense scores, sparsifier).
+// merge_lists    one workgroup per query: exact top-k of best-first lists (per tile or per shard).
+#pragma once
+
+#include "msr_select.hpp"
+
+namespace msr {
+
+// ------------------------------------------------------------------------------------------------ kernel 1
+// <docs per tile, threads, 1-KiB chunk loads per register bank, min waves per SIMD, candidate-key capacity (>= k), diag>
+template <int TILE_DOCS, int NT, int U, int MIN_WAVES, int CAND, bool DBG, int MODE = 0>
+__global__ __launch_bounds__(NT, MIN_WAVES) void score_tiles(const ScoreArgs a) {
+    constexpr int NW = NT / 64;
+    static_assert(TILE_DOCS % (4 * NT) == 0, "tile must be a multiple of 4*NT");
+    static_assert(NT >= kQtBlock, "the staging scan uses the first 256 threads");
+    using L = TileLds<TILE_DOCS, NT, CAND>;
+
+    __shared__ __attribute__((aligned(16))) uint8_t lds[L::kTotal];
+    uint32_t* const acc = reinterpret_cast<uint32_t*>(lds);
+    uint8_t* const un = lds + L::kAcc;
+    // streaming-phase view of the union
+    uint32_t* const seg_start = reinterpret_cast<uint32_t*>(un);
+    uint32_t* const seg_len = seg_start + kQtBlock;
+    uint32_t* const seg_w = seg_len + kQtBlock;
+    uint32_t* const pref = seg_w + kQtBlock;
+    uint32_t* const wsum = pref + kQtBlock + 4;
+    // select-phase view of the union
+    uint64_t* const cand = reinterpret_cast<uint64_t*>(un);
+    uint32_t* const tmax = reinterpret_cast<uint32_t*>(un + L::kUnion);
+    uint32_t* const wmax = tmax + NT;
+    SelectScratch& ss = *reinterpret_cast<SelectScratch*>(un + L::kUnion + L::kTmax);
+
+    const uint32_t tid = threadIdx.x;
+    const uint32_t lane = tid & 63;
+    const uint32_t wave = rfl(tid >> 6);        // provably wave-uniform for the compiler
+    // diagnostic build only: wave 0 stamps s_memtime at phase boundaries and adds the deltas to a side buffer
+    long long t_prev = 0;
+    auto stamp = [&](int slot) {
+        if (DBG && (a.dbg & 8u) && a.stamps && tid == 0 && (blockIdx.x & 63u) == 0) {  // 1 workgroup in 64
+            const long long now = clock64();
+            if (slot >= 0) atomicAdd(&a.stamps[slot], (unsigned long long)(now - t_prev));
+            t_prev = now;
+        }
+    };
+    stamp(-1);
+    if (DBG && (a.dbg & 128u)) return;  // ablation: workgroup launch cost only
+    const uint32_t tile_l = blockIdx.x / a.qn;  // tile-major: neighbours in dispatch order share the tile
+    const uint32_t q = a.q0 + blockIdx.x % a.qn;
+    const uint32_t tile_g = a.tile0 + tile_l;
+    const uint64_t doc0 = (uint64_t)tile_g * TILE_DOCS;
+    const uint32_t ndocs_tile = (uint32_t)min((uint64_t)TILE_DOCS, a.n_docs - doc0);
+    // rounds of 4*NT accumulators that hold real docs
+    const int rounds = (int)((ndocs_tile + 4 * NT - 1) / (4 * NT));
+    uint4* const a4 = reinterpret_cast<uint4*>(acc);
+
+    const uint32_t qb = a.q_ptr[q], qe = a.q_ptr[q + 1];
+    const uint32_t* seg_row = a.seg_ptr + (uint64_t)tile_l * (a.n_terms + 1);
+    const uint4* post4 = reinterpret_cast<const uint4*>(a.postings);
+
+    // ---- first round's (term -> segment) lookups: two dependent global loads, issued before the zeroing so that
+    // their latency hides behind it
+    uint32_t pre_w = 0, pre_s0 = 0, pre_s1 = 0;
+    if (tid < min((uint32_t)kQtBlock, qe - qb)) {
+        const uint32_t t = a.q_term[qb + tid];
+        pre_w = a.q_w[qb + tid];
+        pre_s0 = seg_row[t];
+        pre_s1 = seg_row[t + 1];
+    }
+
+    // ---- initialise the accumulators: zero, or — when the query holds dense-head terms — their whole contribution.
+    // Thread `tid` owns vecs r*NT + tid (4 consecutive docs each); the dense head is doc-major, one dword per doc and
+    // term pair, so the owner scores two postings per v_dot2_u32_u16 and stores the sums with a plain ds_write_b128:
+    // no atomics, and no separate zeroing pass. Term pairs the query does not hold are skipped (wave-uniform bit
+    // mask); the rows of the next pair are in flight while the current pair is accumulated (two register banks).
+    {
+        typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+        constexpr int RG = 4;  // rounds per register group
+        const uint32_t qv = lane < a.n_pairs ? a.q_dense[(uint64_t)q * a.n_pairs + lane] : 0u;
+        const unsigned long long pmask = (DBG && (a.dbg & 16u)) ? 0ull : __ballot(qv != 0);
+        const uint4* dblk = reinterpret_cast<const uint4*>(a.dense) + (uint64_t)tile_l * a.n_pairs * (TILE_DOCS / 4);
+        for (int r0 = 0; r0 < rounds; r0 += RG) {
+            uint4 sacc[RG];
+#pragma unroll
+            for (int i = 0; i < RG; ++i) sacc[i] = make_uint4(0, 0, 0, 0);
+            if (pmask) {
+                auto load_rows = [&](uint4 (&x)[RG], uint32_t p) {
+#pragma unroll
+                    for (int i = 0; i < RG; ++i)  // rows past `rounds` re-read the last real round (result unused)
+                        x[i] = dblk[(uint64_t)p * (TILE_DOCS / 4) + (uint32_t)min(r0 + i, rounds - 1) * NT + tid];
+                };
+                auto add_rows = [&](const uint4 (&x)[RG], uint32_t qp) {
+                    const us2 qq = __builtin_bit_cast(us2, qp);
+#pragma unroll
+                    for (int i = 0; i < RG; ++i) {
+                        sacc[i].x = __builtin_amdgcn_udot2(__builtin_bit_cast(us2, x[i].x), qq, sacc[i].x, false);
+                        sacc[i].y = __builtin_amdgcn_udot2(__builtin_bit_cast(us2, x[i].y), qq, sacc[i].y, false);
+                        sacc[i].z = __builtin_amdgcn_udot2(__builtin_bit_cast(us2, x[i].z), qq, sacc[i].z, false);
+                        sacc[i].w = __builtin_amdgcn_udot2(__builtin_bit_cast(us2, x[i].w), qq, sacc[i].w, false);
+                    }
+                };
+                unsigned long long m = pmask;
+                uint4 xa[RG], xb[RG];
+                uint32_t pa = (uint32_t)__builtin_ctzll(m), pb = 0;
+                m &= m - 1;
+                load_rows(xa, pa);
+                for (;;) {
+                    const bool more_b = m != 0;
+                    if (more_b) {
+                        pb = (uint32_t)__builtin_ctzll(m);
+                        m &= m - 1;
+                        load_rows(xb, pb);
+                    }
+                    add_rows(xa, rdl(qv, pa));
+                    if (!more_b) break;
+                    const bool more_a = m != 0;
+                    if (more_a) {
+                        pa = (uint32_t)__builtin_ctzll(m);
+                        m &= m - 1;
+                        load_rows(xa, pa);
+                    }
+                    add_rows(xb, rdl(qv, pb));
+                    if (!more_a) break;
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < RG; ++i)
+                if (r0 + i < rounds) a4[(r0 + i) * NT + tid] = sacc[i];
+        }
+    }
+    if (tid < 64) ss.cnt[tid] = 0;
+    if (tid == 0) {
+        ss.n_cand = 0;
+        ss.tau0 = 1;
+        ss.smax = 0;
+    }
+
+    for (uint32_t base = qb; base < qe; base += kQtBlock) {
+        const uint32_t cnt = min((uint32_t)kQtBlock, qe - base);
+        if (base != qb) __syncthreads();  // the previous round's readers of seg_* / pref are done (the accumulator
+                                          // init is ordered before the atomics by the two barriers below)
+        stamp(0);  // zeroing (+ q_ptr fetch)
+        // ---- stage the round's segments and an exclusive prefix sum of their chunk counts
+        uint32_t nch = 0;
+        if (tid < kQtBlock) {
+            if (tid < cnt) {
+                uint32_t s0 = pre_s0, s1 = pre_s1, w = pre_w;
+                if (base != qb) {
+                    const uint32_t t = a.q_term[base + tid];
+                    s0 = seg_row[t];
+                    s1 = seg_row[t + 1];
+                    w = a.q_w[base + tid];
+                }
+                seg_start[tid] = s0 - a.vec_base;
+                seg_len[tid] = s1 - s0;
+                seg_w[tid] = w;
+                nch = (s1 - s0 + kChunkVecs - 1) / kChunkVecs;
+            }
+            const uint32_t inc = wave_inclusive_scan_u32(nch);
+            if (lane == 63) wsum[wave] = inc;
+            nch = inc - nch;  // exclusive within the wave
+        }
+        __syncthreads();
+        if (tid < kQtBlock) {
+            uint32_t off = 0;
+            for (uint32_t w = 0; w < wave; ++w) off += wsum[w];
+            pref[tid] = nch + off;
+            if (tid == kQtBlock - 1) pref[kQtBlock] = off + wsum[wave];
+        }
+        __syncthreads();
+        // ---- the round's chunks are dealt round-robin to the waves (chunk c -> wave c % NW), which spreads the
+        // dense head terms and the one-chunk tail terms evenly. The (term, offset) of a wave's next 64 chunks is
+        // resolved lane-parallel (one binary search per lane), then broadcast chunk by chunk with v_readlane, so
+        // the inner loop is scalar control + one 16-byte load and four LDS atomics per lane.
+        stamp(1);  // staging: segment table + chunk-count scan
+        if (DBG && (a.dbg & 64u)) break;  // ablation: stop after staging
+        const uint32_t total = rfl(pref[kQtBlock]);
+        const uint32_t c_end = total > wave ? (total - wave + NW - 1) / NW : 0u;  // chunks of this wave
+        for (uint32_t cb = 0; cb < c_end; cb += 64) {
+            const uint32_t my_i = cb + lane;
+            uint32_t m_base = 0, m_n = 0, m_w = 0;
+            if (my_i < c_end) {
+                const uint32_t my_c = wave + my_i * NW;
+                uint32_t lo = 0, hi = cnt;  // largest lo with pref[lo] <= my_c
+                while (hi - lo > 1) {
+                    const uint32_t mid = (lo + hi) >> 1;
+                    if (pref[mid] <= my_c)
+                        lo = mid;
+                    else
+                        hi = mid;
+                }
+                const uint32_t voff = (my_c - pref[lo]) * kChunkVecs;
+                m_base = seg_start[lo] + voff;
+                m_n = min((uint32_t)kChunkVecs, seg_len[lo] - voff);
+                m_w = seg_w[lo];
+            }
+            stamp(7);  // lane-parallel chunk resolution (binary search)
+            if (DBG && (a.dbg & 256u)) break;  // ablation: stop after the first chunk resolution
+            const uint32_t nchunk = min(64u, c_end - cb);
+            // Software pipeline, two register banks of U chunks: the next bank's 1-KiB loads are in flight while
+            // the current bank's LDS atomics issue. Loads are unconditional (lanes past a chunk's end, and chunk
+            // slots past nchunk, re-read the chunk's / the shard's first vec) so that the compiler can count them
+            // with s_waitcnt vmcnt(N) instead of draining to vmcnt(0); only the atomics are predicated.
+            auto load_bank = [&](uint4 (&v)[U], uint32_t u0) {
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const uint32_t idx = (u0 + u) & 63u;
+                    const uint32_t b = rdl(m_base, idx);
+                    const uint32_t n = rdl(m_n, idx);
+                    if (DBG && (a.dbg & 2u)) {  // ablation: no global loads, synthetic postings
+                        const uint32_t hsh = ((cb + idx) * 64u + lane) * 2654435761u;
+                        v[u] = make_uint4((1u << 16) | (hsh >> 17), (1u << 16) | ((hsh * 31u) >> 17),
+                                          (1u << 16) | ((hsh * 131u) >> 17), (1u << 16) | ((hsh * 1031u) >> 17));
+                    } else {
+                        v[u] = post4[b + (lane < n ? lane : 0u)];
+                    }
+                }
+            };
+            auto add_bank = [&](const uint4 (&v)[U], uint32_t u0) {
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const uint32_t idx = u0 + u;
+                    const uint32_t n = idx < nchunk ? rdl(m_n, idx & 63u) : 0u;
+                    const uint32_t w = rdl(m_w, idx & 63u);
+                    // lanes past the chunk's last vec must not touch LDS (64 lanes adding to one accumulator would
+                    // serialise); padding INSIDE a vec has weight 0 and a lane-distinct ordinal
+                    if (lane < n) {
+                        const uint32_t p[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+                        if (DBG && (a.dbg & 1u)) {  // ablation: no LDS atomics (keep the loads alive)
+                            if ((p[0] ^ p[1] ^ p[2] ^ p[3]) == 0xDEADBEEFu) atomicAdd(&acc[0], 1u);
+                        } else {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e)
+                                atomicAdd(&acc[DBG ? (p[e] & 0xFFFFu) % TILE_DOCS : (p[e] & 0xFFFFu)],
+                                          __umul24(p[e] >> 16, w));
+                        }
+                    }
+                }
+            };
+            uint4 va[U], vb[U];
+            load_bank(va, 0);
+            for (uint32_t u0 = 0; u0 < nchunk; u0 += 2 * U) {
+                const bool more = u0 + U < nchunk;  // wave-uniform
+                if (more) load_bank(vb, u0 + U);
+                add_bank(va, u0);
+                if (more) {
+                    if (u0 + 2 * U < nchunk) load_bank(va, u0 + 2 * U);
+                    add_bank(vb, u0 + U);
+                }
+            }
+        }
+    }
+    stamp(2);  // wave 0's own streaming
+    __syncthreads();  // accumulation complete; the staging view of the union is dead from here on
+    stamp(3);  // waiting for the slowest wave
+
+    // =============================================================== exact top-k of this tile
+    // Thread `tid` owns vec r*NT + tid of the accumulators in round r (conflict-free ds_read_b128); the
+    // accumulators are re-read from LDS in every pass instead of being held in registers.
+    if (MODE == 1) {  // term-sharded search: hand the partial sums of this tile to the reduction
+        const uint32_t g = tile_g / a.tpr, t = tile_g % a.tpr;
+        uint4* dst = reinterpret_cast<uint4*>(a.dump + (((uint64_t)g * a.qn + (q - a.q0)) * a.tpr + t) * TILE_DOCS);
+        for (int r = 0; r < rounds; ++r) {
+            uint4 x = a4[r * NT + tid];
+            if (a.dump_add) {
+                const uint4 o = dst[r * NT + tid];
+                x = make_uint4(x.x + o.x, x.y + o.y, x.z + o.z, x.w + o.w);
+            }
+            dst[r * NT + tid] = x;
+        }
+        return;
+    }
+    uint64_t* out = a.part + ((uint64_t)tile_l * a.nq + q) * a.k;
+    const int k = (int)a.k;
+    if (DBG && (a.dbg & 4u)) {  // ablation: no select phase
+        for (int i = tid; i < k; i += NT) out[i] = 0;
+        return;
+    }
+
+    tile_select<TILE_DOCS, NT, CAND>(a4, cand, tmax, wmax, ss, rounds, doc0, k, out, stamp);
+    stamp(6);  // ranking + output
+}
+
+// ------------------------------------------------------------------------------------------------ kernel 1b
+// Term-sharded search, after the reduce-scatter: rank `rank` holds the SUMMED accumulators of its doc range,
+// src[(qi * tpr + t) * TILE_DOCS + i]; one workgroup per (tile of the range, query) selects the exact tile top-k.
+
+
+template <int TILE_DOCS, int NT, int CAND>
+__global__ __launch_bounds__(NT) void select_tiles(const SelectArgs a) {
+    using L = TileLds<TILE_DOCS, NT, CAND>;
+    __shared__ __attribute__((aligned(16))) uint8_t lds[L::kTotal];
+    uint4* const a4 = reinterpret_cast<uint4*>(lds);
+    uint8_t* const un = lds + L::kAcc;
+    uint64_t* const cand = reinterpret_cast<uint64_t*>(un);
+    uint32_t* const tmax = reinterpret_cast<uint32_t*>(un + L::kUnion);
+    uint32_t* const wmax = tmax + NT;
+    SelectScratch& ss = *reinterpret_cast<SelectScratch*>(un + L::kUnion + L::kTmax);
+    const uint32_t tid = threadIdx.x;
+    const uint32_t t = blockIdx.x / a.qn, qi = blockIdx.x % a.qn;
+    const uint32_t tile_g = a.rank * a.tpr + t;
+    uint64_t* out = a.part + ((uint64_t)t * a.nq + a.q0 + qi) * a.k;
+    if (tile_g >= a.n_tiles) {  // padding tile of the last rank
+        for (uint32_t i = tid; i < a.k; i += NT) out[i] = 0;
+        return;
+    }
+    const uint64_t doc0 = (uint64_t)tile_g * TILE_DOCS;
+    const uint32_t ndocs_tile = (uint32_t)min((uint64_t)TILE_DOCS, a.n_docs - doc0);
+    const int rounds = (int)((ndocs_tile + 4 * NT - 1) / (4 * NT));
+    const uint4* src = reinterpret_cast<const uint4*>(a.src + ((uint64_t)qi * a.tpr + t) * TILE_DOCS);
+    for (int r = 0; r < rounds; ++r) a4[r * NT + tid] = src[r * NT + tid];
+    if (tid < 64) ss.cnt[tid] = 0;
+    if (tid == 0) {
+        ss.n_cand = 0;
+        ss.tau0 = 1;
+        ss.smax = 0;
+    }
+    __syncthreads();
+    tile_select<TILE_DOCS, NT, CAND>(a4, cand, tmax, wmax, ss, rounds, doc0, (int)a.k, out, [](int) {});
+}
+
+// ------------------------------------------------------------------------------------------------ kernel 2
+
+
+template <int NT>
+__global__ __launch_bounds__(NT) void merge_lists(const MergeArgs a) {
+    __shared__ __attribute__((aligned(16))) uint64_t cand[kCandCap];
+    __shared__ uint64_t res[kCandCap];
+    __shared__ SelectScratch ss;
+    __shared__ uint64_t wmax[NT / 64];
+
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t q = blockIdx.x;
+    const int k = (int)a.k;
+    const uint32_t n_items = a.n_lists * a.k;
+    auto key_at = [&](uint32_t i) -> uint64_t {
+        const uint32_t l = i / a.k, j = i - l * a.k;
+        return a.lists[(uint64_t)l * a.list_stride + (uint64_t)q * a.k + j];
+    };
+    if (tid < 64) ss.cnt[tid] = 0;
+    if (tid == 0) ss.n_cand = 0;
+    __syncthreads();
+
+    uint32_t n_cand;
+    if (n_items <= kCandCap) {
+        for (uint32_t i = tid; i < n_items; i += NT) {
+            const uint64_t key = key_at(i);
+            if (key) cand[atomicAdd(&ss.n_cand, 1u)] = key;
+        }
+        __syncthreads();
+        n_cand = ss.n_cand;
+    } else {
+        // More keys than the LDS buffer holds. Every list is sorted best-first, so the k-th largest of the lists'
+        // HEAD keys is a lower bound on the global k-th key (when there are at least k non-empty lists); keys at or
+        // above it are few. If they do not fit either (or there are fewer than k lists), bisect over all keys.
+        auto bisect_kth = [&](uint32_t n, auto key_of) -> uint64_t {  // k-th largest of n keys (0 if fewer than k > 0)
+            uint64_t m = 0;
+            for (uint32_t i = tid; i < n; i += NT) {
+                const uint64_t key = key_of(i);
+                m = key > m ? key : m;
+            }
+            m = wave_max_u64(m);
+            __syncthreads();  // previous users of wmax / cnt are done
+            if (lane == 0) wmax[wave] = m;
+            if (tid < 64) ss.cnt[tid] = 0;
+            __syncthreads();
+            m = 0;
+            for (int w = 0; w < NT / 64; ++w) m = wmax[w] > m ? wmax[w] : m;
+            uint64_t tau = 0;
+            if (m) {
+                int step = 0;
+                for (int bit = 63 - __clzll((long long)m); bit >= 0; --bit, ++step) {
+                    const uint64_t t2 = tau | (1ull << bit);
+                    uint32_t c = 0;
+                    for (uint32_t i = tid; i < n; i += NT) c += key_of(i) >= t2;
+                    c = wave_sum_u32(c);
+                    if (lane == 0 && c) atomicAdd(&ss.cnt[step], c);  // at most 64 steps: one slot each
+                    __syncthreads();
+                    if (ss.cnt[step] >= (uint32_t)k) tau = t2;
+                }
+            }
+            return tau;
+        };
+        auto collect = [&](uint64_t tau) {
+            __syncthreads();
+            if (tid == 0) ss.n_cand = 0;
+            __syncthreads();
+            for (uint32_t i = tid; i < n_items; i += NT) {
+                const uint64_t key = key_at(i);
+                if (key && key >= tau) {
+                    const uint32_t pos = atomicAdd(&ss.n_cand, 1u);
+                    if (pos < kCandCap) cand[pos] = key;
+                }
+            }
+            __syncthreads();
+            return ss.n_cand;
+        };
+        uint32_t got = kCandCap + 1;
+        if (a.n_lists >= (uint32_t)k) {
+            const uint64_t tau_heads = bisect_kth(a.n_lists, [&](uint32_t l) { return key_at(l * a.k); });
+            if (tau_heads) got = collect(tau_heads);
+        }
+        if (got > kCandCap) got = collect(bisect_kth(n_items, key_at));  // exactly min(k, #keys) <= kCandCap survive
+        n_cand = min(got, (uint32_t)kCandCap);
+    }
+    rank_and_emit<NT>(cand, (int)n_cand, k, res);
+    __syncthreads();
+    const int n_hit = min((int)n_cand, k);
+    for (int i = tid; i < k; i += NT) {
+        const uint64_t key = res[i];
+        const uint64_t o = (uint64_t)q * a.k + i;
+        if (a.out_keys) a.out_keys[o] = key;
+        if (a.out_ord) {
+            const uint32_t sc = (uint32_t)(key >> 32);
+            a.out_ord[o] = key ? 0xFFFFFFFFu - (uint32_t)key : 0xFFFFFFFFu;
+            a.out_score_u32[o] = sc;
+            a.out_score[o] = (float)sc;  // round-to-nearest-even, exact below 2^24 (contract T5)
+        }
+    }
+    if (tid == 0 && a.out_n) a.out_n[q] = n_hit;
+}
+
+}  // namespace msr

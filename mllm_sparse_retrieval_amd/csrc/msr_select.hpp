@@ -1,0 +1,278 @@
+// Device-side building blocks shared by every kernel: cross-lane reductions (DPP), the order-preserving f32 <-> u32
+// key map, the LDS carve of an accumulator tile and the exact per-tile top-k (tile_select).
+#pragma once
+
+#include "msr_device_internal.hpp"
+
+namespace msr {
+
+// ------------------------------------------------------------------------------------------------ device helpers
+__device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+// Unsigned max across lanes with DPP (VALU cross-lane operands, no LDS round trip like ds_bpermute):
+// quad_perm [1,0,3,2] -> quad_perm [2,3,0,1] -> row_half_mirror -> row_mirror leave every lane of a 4 / 8 / 16-lane
+// group with the group's maximum; row_bcast:15 / row_bcast:31 then carry the row maxima into lane 63.
+template <int CTRL, int ROW_MASK = 0xF>
+__device__ __forceinline__ uint32_t dpp_umax(uint32_t v) {
+    const uint32_t o = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, 0xF, false);  // unwritten lanes: 0
+    return max(v, o);
+}
+template <int G>  // maximum of every aligned group of G = 1, 2, 4, 8 or 16 lanes, in all lanes of the group
+__device__ __forceinline__ uint32_t group_max_u32(uint32_t v) {
+    if (G >= 2) v = dpp_umax<0xB1>(v);
+    if (G >= 4) v = dpp_umax<0x4E>(v);
+    if (G >= 8) v = dpp_umax<0x141>(v);
+    if (G >= 16) v = dpp_umax<0x140>(v);
+    return v;
+}
+// Inclusive prefix sum over the 64 lanes with DPP: row_shr 1, 2, 4, 8 build the scan inside every 16-lane row, then
+// row_bcast:15 / row_bcast:31 add the totals of the preceding rows.
+template <int CTRL, int ROW_MASK = 0xF, int BANK_MASK = 0xF>
+__device__ __forceinline__ uint32_t dpp_add(uint32_t v) {
+    return v + (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, BANK_MASK, false);  // unwritten lanes add 0
+}
+__device__ __forceinline__ uint32_t wave_inclusive_scan_u32(uint32_t v) {
+    v = dpp_add<0x111>(v);             // row_shr:1
+    v = dpp_add<0x112>(v);             // row_shr:2
+    v = dpp_add<0x114, 0xF, 0xE>(v);   // row_shr:4
+    v = dpp_add<0x118, 0xF, 0xC>(v);   // row_shr:8
+    v = dpp_add<0x142, 0xA>(v);        // row_bcast:15 into rows 1 and 3
+    v = dpp_add<0x143, 0xC>(v);        // row_bcast:31 into rows 2 and 3
+    return v;
+}
+__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
+    v = group_max_u32<16>(v);
+    v = dpp_umax<0x142, 0xA>(v);  // row_bcast:15 into rows 1 and 3
+    v = dpp_umax<0x143, 0xC>(v);  // row_bcast:31 into rows 2 and 3
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
+__device__ __forceinline__ uint64_t wave_max_u64(uint64_t v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        uint64_t other = __shfl_xor(v, o, 64);
+        v = other > v ? other : v;
+    }
+    return v;
+}
+
+__device__ __forceinline__ uint32_t rfl(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+__device__ __forceinline__ uint32_t rdl(uint32_t v, uint32_t l) { return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)l); }
+
+// Rank-by-counting over `n` UNIQUE non-zero keys in LDS: key with rank r < k goes to out[r]; slots [n, k) get 0.
+template <int NT>
+__device__ __forceinline__ void rank_and_emit(const uint64_t* cand, int n, int k, uint64_t* __restrict__ out) {
+    if (n <= 64) {
+        // one wave, keys in registers, partner keys broadcast with v_readlane (no LDS round trips)
+        if (threadIdx.x < 64) {
+            const int lane = (int)threadIdx.x;
+            const uint64_t me = lane < n ? cand[lane] : 0ull;
+            const uint32_t lo = (uint32_t)me, hi = (uint32_t)(me >> 32);
+            int rank = 0;
+            for (int j = 0; j < n; ++j) {
+                const uint64_t o = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)hi, j) << 32) |
+                                   (uint32_t)__builtin_amdgcn_readlane((int)lo, j);
+                rank += o > me;
+            }
+            if (lane < n && rank < k) out[rank] = me;
+            for (int i = n + lane; i < k; i += 64) out[i] = 0;
+        }
+        return;
+    }
+    for (int i = threadIdx.x; i < n; i += NT) {
+        const uint64_t me = cand[i];
+        int rank = 0;
+        for (int j = 0; j < n; ++j) rank += cand[j] > me;
+        if (rank < k) out[rank] = me;
+    }
+    for (int i = n + (int)threadIdx.x; i < k; i += NT) out[i] = 0;
+}
+
+struct SelectScratch {
+    uint32_t cnt[64];  // one counter per bisection step
+    uint32_t n_cand;
+    uint32_t tau0;
+    uint32_t smax;
+    uint32_t pad;
+};
+
+__device__ __forceinline__ uint32_t f32_to_key(float f) {  // monotone: a < b  <=>  key(a) < key(b); never 0 for finite f
+    const uint32_t u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+
+__device__ __forceinline__ float key_to_f32(uint32_t key) {
+    return __uint_as_float((key & 0x80000000u) ? (key & 0x7FFFFFFFu) : ~key);
+}
+
+
+
+// LDS carve (bytes). The staging arrays of the streaming phase and the candidate keys of the select phase are
+// never live together, so they share one region.
+template <int TILE_DOCS, int NT, int CAND>
+struct TileLds {
+    static constexpr int kAcc = TILE_DOCS * 4;
+    static constexpr int kStage = kQtBlock * 4 * 3 + (kQtBlock + 4) * 4 + 8 * 4;  // seg_start/len/w, pref, wsum
+    static constexpr int kCand = CAND * 8;
+    static constexpr int kUnion = (kStage > kCand ? kStage : kCand);
+    static constexpr int kTmax = NT * 4 + 64 * 4;  // per-thread maxima (k > waves) + per-wave maxima
+    static constexpr int kTotal = kAcc + kUnion + kTmax + (int)sizeof(SelectScratch);
+};
+
+
+// Exact top-k of one accumulator tile held in LDS (shared by score_tiles and select_tiles).
+// Thread `tid` owns vec r*NT + tid of the accumulators in round r (conflict-free ds_read_b128); the accumulators are
+// re-read from LDS in every pass instead of being held in registers. Writes k keys best-first (0 = empty slot).
+template <int TILE_DOCS, int NT, int CAND, class Stamp>
+__device__ __forceinline__ void tile_select(const uint4* a4, uint64_t* cand, uint32_t* tmax, uint32_t* wmax,
+                                            SelectScratch& ss, int rounds, uint64_t doc0, int k,
+                                            uint64_t* __restrict__ out, Stamp stamp) {
+    constexpr int NW = NT / 64;
+    const uint32_t tid = threadIdx.x;
+    const uint32_t lane = tid & 63;
+    const uint32_t wave = rfl(tid >> 6);
+    uint32_t mymax = 0;
+    for (int r = 0; r < rounds; ++r) {
+        const uint4 x = a4[r * NT + tid];
+        mymax = max(max(mymax, max(x.x, x.y)), max(x.z, x.w));
+    }
+    // ---- tau0: a lower bound with at least k accumulators at or above it = the k-th largest GROUP maximum.
+    //   k <= 64 : 64 groups of NT/64 consecutive threads (log2(NT/64) shuffle steps), then every wave bisects the
+    //             64 group maxima with ballots (no further barrier);
+    //   k >  64 : groups are single threads (NT maxima, NT/64 per lane of wave 0), one more barrier.
+    constexpr int G = NT / 64;  // threads per group
+    static_assert(G == 4 || G == 8 || G == 16, "group maxima use the 4/8/16-lane DPP reductions");
+    const uint32_t gm = group_max_u32<G>(mymax);
+    if ((lane & (G - 1)) == 0) wmax[tid / G] = gm;
+    if (k > 64) tmax[tid] = mymax;
+    __syncthreads();
+
+    uint32_t tau0 = 1, smax;
+    {
+        const uint32_t v = wmax[lane];  // 64 group maxima, one per lane, in every wave
+        smax = wave_max_u32(v);
+        if (smax == 0) {  // nothing matched in this tile
+            for (int i = tid; i < k; i += NT) out[i] = 0;
+            return;
+        }
+        if (k <= 64) {
+            uint32_t tau = 0;
+            for (int bit = 31 - __clz(smax); bit >= 0; --bit) {
+                const uint32_t t2 = tau | (1u << bit);
+                if (__popcll(__ballot(v >= t2)) >= k) tau = t2;
+            }
+            tau0 = max(tau, 1u);
+        }
+    }
+    if (k > 64 && k <= NT) {
+        if (wave == 0) {
+            uint32_t mine[NW];
+#pragma unroll
+            for (int i = 0; i < NW; ++i) mine[i] = tmax[i * 64 + lane];
+            uint32_t tau = 0;
+            for (int bit = 31 - __clz(smax); bit >= 0; --bit) {
+                const uint32_t t2 = tau | (1u << bit);
+                uint32_t c = 0;
+#pragma unroll
+                for (int i = 0; i < NW; ++i) c += (uint32_t)__popcll(__ballot(mine[i] >= t2));
+                if (c >= (uint32_t)k) tau = t2;
+            }
+            if (lane == 0) ss.tau0 = max(tau, 1u);
+        }
+        __syncthreads();
+        tau0 = ss.tau0;
+    }
+
+    stamp(4);  // thread / wave maxima, tau0
+    // ---- candidates: accumulators >= tau0 as unique global keys (score << 32 | ~ordinal)
+    if (mymax >= tau0) {
+        for (int r = 0; r < rounds; ++r) {
+            const uint4 x = a4[r * NT + tid];
+            const uint32_t sc4[4] = {x.x, x.y, x.z, x.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (sc4[e] >= tau0) {
+                    const uint32_t local = 4 * (r * NT + tid) + e;
+                    const uint32_t pos = atomicAdd(&ss.n_cand, 1u);
+                    if (pos < CAND)
+                        cand[pos] = ((uint64_t)sc4[e] << 32) | (uint64_t)(0xFFFFFFFFu - (uint32_t)(doc0 + local));
+                }
+        }
+    }
+    __syncthreads();
+    stamp(5);  // candidate collection
+    uint32_t n_cand = ss.n_cand;
+
+    if (n_cand > CAND) {
+        // ---- fallback (mass ties, or k in the hundreds): exact selection by bisection.
+        //   1. tau = k-th largest SCORE of the tile: one bit per step, counted with ballots (scalar popcounts);
+        //   2. every accumulator above tau is in; of the c_eq accumulators equal to tau the `need` lowest ordinals are
+        //      in — found by a second bisection over the local ordinal only when there are more ties than needed.
+        // Exactly min(k, #positive) <= CAND keys survive.
+        __syncthreads();  // everyone has read n_cand
+        if (tid == 0) ss.n_cand = 0;
+        auto count_if = [&](auto pred) -> uint32_t {  // wave-level count over this wave's accumulators (uniform)
+            uint32_t c = 0;
+            for (int r = 0; r < rounds; ++r) {
+                const uint4 x = a4[r * NT + tid];
+                const uint32_t base = 4 * (r * NT + tid);
+                c += (uint32_t)__popcll(__ballot(pred(x.x, base))) + (uint32_t)__popcll(__ballot(pred(x.y, base + 1))) +
+                     (uint32_t)__popcll(__ballot(pred(x.z, base + 2))) + (uint32_t)__popcll(__ballot(pred(x.w, base + 3)));
+            }
+            return c;
+        };
+        int step = 0;
+        auto block_count = [&](uint32_t c) -> uint32_t {  // sum of the waves' counts, the same value on every thread
+            if (lane == 0 && c) atomicAdd(&ss.cnt[step], c);
+            __syncthreads();
+            return ss.cnt[step++];
+        };
+        uint32_t tau = 0;
+        for (int bit = 31 - __clz(smax); bit >= 0; --bit) {
+            const uint32_t t2 = tau | (1u << bit);
+            if (block_count(count_if([&](uint32_t sc, uint32_t) { return sc >= t2; })) >= (uint32_t)k) tau = t2;
+        }
+        uint32_t o_star = 0xFFFFFFFFu;  // ties at tau with local ordinal <= o_star are selected
+        if (tau == 0) {
+            tau = 1;  // fewer than k positive accumulators: all of them
+        } else {
+            const uint32_t c_gt = block_count(count_if([&](uint32_t sc, uint32_t) { return sc > tau; }));
+            const uint32_t c_eq = block_count(count_if([&](uint32_t sc, uint32_t) { return sc == tau; }));
+            const uint32_t need = (uint32_t)k - c_gt;  // >= 1 by the definition of tau
+            if (c_eq > need) {
+                uint32_t lo = 0, hi = TILE_DOCS - 1;  // smallest o with #(ties, local <= o) >= need
+                while (lo < hi) {
+                    const uint32_t mid = (lo + hi) >> 1;
+                    const uint32_t c = block_count(count_if([&](uint32_t sc, uint32_t loc) { return sc == tau && loc <= mid; }));
+                    if (c >= need)
+                        hi = mid;
+                    else
+                        lo = mid + 1;
+                }
+                o_star = lo;
+            }
+        }
+        __syncthreads();
+        for (int r = 0; r < rounds; ++r) {
+            const uint4 x = a4[r * NT + tid];
+            const uint32_t sc4[4] = {x.x, x.y, x.z, x.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const uint32_t local = 4 * (r * NT + tid) + e;
+                if (sc4[e] > tau || (sc4[e] == tau && local <= o_star)) {
+                    const uint32_t pos = atomicAdd(&ss.n_cand, 1u);
+                    if (pos < CAND)
+                        cand[pos] = ((uint64_t)sc4[e] << 32) | (uint64_t)(0xFFFFFFFFu - (uint32_t)(doc0 + local));
+                }
+            }
+        }
+        __syncthreads();
+        n_cand = min(ss.n_cand, (uint32_t)CAND);  // == min(k, #positive) <= CAND by construction
+    }
+    rank_and_emit<NT>(cand, (int)n_cand, k, out);
+}
+
+
+}  // namespace msr
