@@ -154,6 +154,9 @@ void device_detach(msr_index* ix) {
     if (!d) return;
     (void)hipSetDevice(d->device);
     if (d->comm) ncclCommDestroy(d->comm);
+    d->pool.purge();
+    for (hipEvent_t e : d->spare_events) (void)hipEventDestroy(e);
+    if (d->h_stage) (void)hipHostFree(d->h_stage);
     if (d->d_seg_ptr) (void)hipFree(d->d_seg_ptr);
     if (d->d_postings) (void)hipFree(d->d_postings);
     if (d->d_dense) (void)hipFree(d->d_dense);
@@ -210,12 +213,25 @@ using namespace msr;
 void batch_free(msr_batch* b) {
     if (!b) return;
     if (b->ix && b->ix->dev) (void)hipSetDevice(b->ix->dev->device);
-    void* ptrs[] = {b->d_qptr, b->d_qterm, b->d_qw, b->d_qdense, b->d_part, b->d_keys, b->d_gather, b->d_ord, b->d_su32, b->d_sf32, b->d_n,
-                    b->d_stamps, b->d_S, b->d_R, b->d_tpart};
+    // d_qptr .. d_n live inside pooled blocks; the rest are plain allocations
+    void* ptrs[] = {b->d_gather, b->d_stamps, b->d_S, b->d_R, b->d_tpart};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
-    for (hipEvent_t e : b->events)
-        if (e) (void)hipEventDestroy(e);
+    DeviceIndex* d = (b->ix && b->ix->dev) ? b->ix->dev : nullptr;
+    if (d && d->stream && !b->pooled.empty()) (void)hipStreamSynchronize(d->stream);  // nothing in flight may still use them
+    for (auto& blk : b->pooled) {
+        if (d)
+            d->pool.release(blk.first, blk.second);
+        else
+            (void)hipFree(blk.first);
+    }
+    for (hipEvent_t e : b->events) {
+        if (!e) continue;
+        if (d && d->spare_events.size() < 64)
+            d->spare_events.push_back(e);
+        else
+            (void)hipEventDestroy(e);
+    }
     delete b;
 }
 
@@ -361,25 +377,66 @@ static int batch_create_impl(msr_index* ix, const int64_t* q_ptr, const int32_t*
     }
     const size_t nqk = std::max<size_t>((size_t)nq * kmax, 1);
     const size_t ntiles = std::max<uint32_t>(ix->shard_ntiles, 1);
-    bool ok = hipMalloc(&b->d_qptr, ((size_t)nq + 1) * 4) == hipSuccess &&
-              hipMalloc(&b->d_qterm, std::max<size_t>(qterm.size(), 1) * 4) == hipSuccess &&
-              hipMalloc(&b->d_qw, std::max<size_t>(qw.size(), 1) * 4) == hipSuccess &&
-              hipMalloc(&b->d_qdense, std::max<size_t>(qdense.size(), 1) * 4) == hipSuccess &&
-              hipMalloc(&b->d_part, ntiles * nqk * 8) == hipSuccess && hipMalloc(&b->d_keys, nqk * 8) == hipSuccess &&
-              hipMalloc(&b->d_ord, nqk * 4) == hipSuccess && hipMalloc(&b->d_su32, nqk * 4) == hipSuccess &&
-              hipMalloc(&b->d_sf32, nqk * 4) == hipSuccess &&
-              hipMalloc(&b->d_n, std::max<size_t>(nq, 1) * 4) == hipSuccess;
-    if (!ok) {
-        set_error("hipMalloc for the query batch failed (%d queries, kmax %d, %zu tiles)", nq, kmax, ntiles);
+    // one input block (q_ptr | q_term | q_w | q_dense) and one output block (ord | u32 scores | f32 scores | n), both
+    // from the handle's caching pool; small batches travel through pinned staging in ONE copy each way
+    auto al = [](size_t n) { return (n + 63) / 64 * 64; };  // sub-buffers start on 256-byte boundaries (in u32 units)
+    const size_t o_ptr = 0, o_term = o_ptr + al((size_t)nq + 1), o_w = o_term + al(qterm.size()),
+                 o_dense = o_w + al(qw.size()), in_words = o_dense + al(qdense.size());
+    const size_t o_ord = 0, o_su = o_ord + al(nqk), o_sf = o_su + al(nqk), o_n = o_sf + al(nqk), out_words = o_n + al((size_t)nq);
+    auto take = [&](size_t bytes) -> void* {
+        void* p = d->pool.alloc(bytes);
+        if (p) b->pooled.emplace_back(p, bytes);
+        return p;
+    };
+    uint32_t* d_in = (uint32_t*)take(std::max<size_t>(in_words, 1) * 4);
+    uint32_t* d_out = (uint32_t*)take(std::max<size_t>(out_words, 1) * 4);
+    b->d_part = (uint64_t*)take(ntiles * nqk * 8);
+    b->d_keys = (uint64_t*)take(nqk * 8);
+    if (!d_in || !d_out || !b->d_part || !b->d_keys) {
+        set_error("device allocation for the query batch failed (%d queries, kmax %d, %zu tiles)", nq, kmax, ntiles);
         return fail(MSR_E_NOMEM);
     }
-    ok = (qdense.empty() || hipMemcpy(b->d_qdense, qdense.data(), qdense.size() * 4, hipMemcpyHostToDevice) == hipSuccess) &&
-         hipMemcpy(b->d_qptr, qptr.data(), ((size_t)nq + 1) * 4, hipMemcpyHostToDevice) == hipSuccess &&
-         (qterm.empty() || (hipMemcpy(b->d_qterm, qterm.data(), qterm.size() * 4, hipMemcpyHostToDevice) == hipSuccess &&
-                            hipMemcpy(b->d_qw, qw.data(), qw.size() * 4, hipMemcpyHostToDevice) == hipSuccess));
-    if (!ok) {
-        set_error("upload of the query batch failed");
-        return fail(MSR_E_HIP);
+    b->d_qptr = d_in + o_ptr;
+    b->d_qterm = d_in + o_term;
+    b->d_qw = d_in + o_w;
+    b->d_qdense = d_in + o_dense;
+    b->d_ord = d_out + o_ord;
+    b->d_su32 = d_out + o_su;
+    b->d_sf32 = reinterpret_cast<float*>(d_out + o_sf);
+    b->d_n = reinterpret_cast<int32_t*>(d_out + o_n);
+    {
+        const size_t in_bytes = in_words * 4;
+        bool ok = true;
+        if (in_bytes <= (8u << 20)) {
+            if (d->h_stage_bytes < in_bytes) {
+                if (d->h_stage) (void)hipHostFree(d->h_stage);
+                d->h_stage = nullptr;
+                d->h_stage_bytes = 0;
+                const size_t want = std::max<size_t>(in_bytes, 1u << 20);
+                if (hipHostMalloc(&d->h_stage, want, hipHostMallocDefault) == hipSuccess) d->h_stage_bytes = want;
+            }
+        }
+        if (d->h_stage && d->h_stage_bytes >= in_bytes && in_bytes <= (8u << 20)) {
+            uint32_t* hs = (uint32_t*)d->h_stage;
+            memcpy(hs + o_ptr, qptr.data(), ((size_t)nq + 1) * 4);
+            if (!qterm.empty()) {
+                memcpy(hs + o_term, qterm.data(), qterm.size() * 4);
+                memcpy(hs + o_w, qw.data(), qw.size() * 4);
+            }
+            if (!qdense.empty()) memcpy(hs + o_dense, qdense.data(), qdense.size() * 4);
+            // synchronous on purpose: the staging buffer is reused by the next call
+            ok = hipMemcpyAsync(d_in, hs, in_bytes, hipMemcpyHostToDevice, d->stream) == hipSuccess &&
+                 hipStreamSynchronize(d->stream) == hipSuccess;
+        } else {
+            ok = hipMemcpy(b->d_qptr, qptr.data(), ((size_t)nq + 1) * 4, hipMemcpyHostToDevice) == hipSuccess &&
+                 (qterm.empty() || (hipMemcpy(b->d_qterm, qterm.data(), qterm.size() * 4, hipMemcpyHostToDevice) == hipSuccess &&
+                                    hipMemcpy(b->d_qw, qw.data(), qw.size() * 4, hipMemcpyHostToDevice) == hipSuccess)) &&
+                 (qdense.empty() || hipMemcpy(b->d_qdense, qdense.data(), qdense.size() * 4, hipMemcpyHostToDevice) == hipSuccess);
+        }
+        if (!ok) {
+            set_error("upload of the query batch failed");
+            return fail(MSR_E_HIP);
+        }
     }
     *out = b;
     return MSR_OK;
@@ -410,7 +467,12 @@ int batch_search_local(msr_batch* b, int k, bool final_arrays) {
     if (b->calls >= 4096) b->calls = 0;  // bounded: callers that never reset keep only the recent calls
     while (b->events.size() < (b->calls + 1) * 3) {
         hipEvent_t e = nullptr;
-        HIP_TRY(hipEventCreate(&e));
+        if (!d->spare_events.empty()) {
+            e = d->spare_events.back();
+            d->spare_events.pop_back();
+        } else {
+            HIP_TRY(hipEventCreate(&e));
+        }
         b->events.push_back(e);
     }
     b->ev0 = b->events[b->calls * 3 + 0];
@@ -510,6 +572,21 @@ int msr_batch_fetch(msr_batch* b, uint32_t* out_doc_ord, float* out_score, uint3
     int rc = msr_batch_sync(b);
     if (rc != MSR_OK) return rc;
     const size_t n = (size_t)b->nq * b->last_k;
+    {
+        // small results: the whole output block in one copy through the pinned staging buffer
+        DeviceIndex* d = b->ix->dev;
+        const size_t span = (size_t)((const uint32_t*)b->d_n - b->d_ord) + (size_t)b->nq;  // words from d_ord to the end of d_n
+        if (n && d->h_stage && span * 4 <= d->h_stage_bytes) {
+            HIP_TRY(hipMemcpyAsync(d->h_stage, b->d_ord, span * 4, hipMemcpyDeviceToHost, d->stream));
+            HIP_TRY(hipStreamSynchronize(d->stream));
+            const uint32_t* hs = (const uint32_t*)d->h_stage;
+            if (out_doc_ord) memcpy(out_doc_ord, hs, n * 4);
+            if (out_score_u32) memcpy(out_score_u32, hs + (b->d_su32 - b->d_ord), n * 4);
+            if (out_score) memcpy(out_score, hs + ((const uint32_t*)b->d_sf32 - b->d_ord), n * 4);
+            if (out_n) memcpy(out_n, hs + ((const uint32_t*)b->d_n - b->d_ord), (size_t)b->nq * 4);
+            return MSR_OK;
+        }
+    }
     if (n) {
         if (out_doc_ord) HIP_TRY(hipMemcpy(out_doc_ord, b->d_ord, n * 4, hipMemcpyDeviceToHost));
         if (out_score) HIP_TRY(hipMemcpy(out_score, b->d_sf32, n * 4, hipMemcpyDeviceToHost));

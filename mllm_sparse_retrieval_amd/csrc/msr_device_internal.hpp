@@ -30,9 +30,55 @@ constexpr int kCandCap = 1024;   // candidate keys per workgroup (>= MSR_KMAX)
 constexpr int kChunkVecs = 64;   // one chunk = one wave-wide uint4 load = 256 postings = 1 KiB
 static_assert(kCandCap >= MSR_KMAX, "candidate buffer must hold k keys");
 
+// Caching device allocator of one index handle. msr_search_csr at the reference's call shape (4 queries per call,
+// scripts/search_sparse.sh:16) would otherwise spend more time in hipMalloc / hipFree than in its kernels.
+struct DevicePool {
+    static constexpr size_t kMaxCachedBlock = 64ull << 20, kMaxCachedTotal = 512ull << 20;
+    std::vector<std::pair<size_t, void*>> free_;  // (bytes, ptr)
+    size_t cached = 0;
+    static size_t round_up(size_t b) {
+        size_t r = 256;
+        while (r < b) r <<= 1;
+        return r;
+    }
+    void* alloc(size_t bytes) {
+        const size_t want = round_up(std::max<size_t>(bytes, 1));
+        for (size_t i = 0; i < free_.size(); ++i)
+            if (free_[i].first == want) {
+                void* p = free_[i].second;
+                free_[i] = free_.back();
+                free_.pop_back();
+                cached -= want;
+                return p;
+            }
+        void* p = nullptr;
+        if (hipMalloc(&p, want) != hipSuccess) return nullptr;
+        return p;
+    }
+    void release(void* p, size_t bytes) {
+        if (!p) return;
+        const size_t have = round_up(std::max<size_t>(bytes, 1));
+        if (have > kMaxCachedBlock || cached + have > kMaxCachedTotal) {
+            (void)hipFree(p);
+            return;
+        }
+        free_.emplace_back(have, p);
+        cached += have;
+    }
+    void purge() {
+        for (auto& e : free_) (void)hipFree(e.second);
+        free_.clear();
+        cached = 0;
+    }
+};
+
 struct DeviceIndex {
     int device = -1;
     hipStream_t stream = nullptr;
+    DevicePool pool;
+    std::vector<hipEvent_t> spare_events;  // recycled by the batches of this handle
+    void* h_stage = nullptr;               // pinned staging for small uploads / downloads
+    size_t h_stage_bytes = 0;
     uint32_t* d_seg_ptr = nullptr;   // [shard_ntiles][n_terms+1] absolute vec index
     uint32_t* d_postings = nullptr;  // the shard's vecs; vec v of the index lives at d_postings + (v - vec_base)*4
     uint32_t* d_dense = nullptr;     // [shard_ntiles][n_pairs][tile_docs] dense head of the shard's tiles
@@ -130,6 +176,7 @@ struct msr_batch {
     uint64_t* d_tpart = nullptr;  // [tpr][nq][kmax] per-tile keys of this rank's doc range
     size_t S_elems = 0, R_elems = 0, tpart_elems = 0;
     int term_shard = -1, term_nshards = 0;  // >= 0: the batch holds only the query terms of that term range
+    std::vector<std::pair<void*, size_t>> pooled;  // blocks taken from the index's DevicePool (the d_* above point into them)
     hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr;  // the current call's events (borrowed from `events`)
     std::vector<hipEvent_t> events;  // 3 per recorded search call since the last timing reset
     size_t calls = 0;                // recorded calls
