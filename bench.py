@@ -239,9 +239,23 @@ def run_headline(args, ranks, m, wlmod):
             for _ in range(50):
                 ix.search_csr(*q4, wl.k)
             small = (time.perf_counter() - t0) / 50
+            # ... and the drop-in class itself on query STRINGS (tokens repeated weight times, src/search.py:419-422)
+            from mllm_sparse_retrieval_amd.compat import LuceneImpactSearcher
+
+            strings = [" ".join(" ".join([str(int(t))] * int(w)) for t, w in zip(qt[qp[i]:qp[i + 1]], qw[qp[i]:qp[i + 1]]))
+                       for i in range(4)]
+            searcher = LuceneImpactSearcher(path, None, device=ranks.local_rank)
+            searcher.batch_search(strings, ["0", "1", "2", "3"], wl.k, threads=16)
+            t0 = time.perf_counter()
+            for _ in range(50):
+                searcher.batch_search(strings, ["0", "1", "2", "3"], wl.k, threads=16)
+            dropin = (time.perf_counter() - t0) / 50
+            searcher.close()
             out["host_inclusive"] = {"queries_per_s_one_call": round(nq / e2e, 1),
                                      "ms_per_call_4_queries": round(small * 1e3, 4),
-                                     "queries_per_s_4_per_call": round(4 / small, 1)}
+                                     "queries_per_s_4_per_call": round(4 / small, 1),
+                                     "ms_per_batch_search_4_query_strings": round(dropin * 1e3, 4),
+                                     "tokens_per_query_string": round(sum(len(x.split()) for x in strings) / 4, 1)}
     batch.close()
     ix.close()
     try:

@@ -112,6 +112,12 @@ int msr_search_csr(msr_index* ix, const int64_t* q_ptr, const int32_t* q_term, c
                    uint32_t flags, uint32_t* out_doc_ord, float* out_score, uint32_t* out_score_u32,
                    int32_t* out_n);
 
+/* The same search for query STRINGS as the reference builds them (each token repeated `weight` times,
+ * src/search.py:419-422): whitespace split, token counts and dictionary lookup happen on the host inside this call —
+ * the work pyserini's batch_search does in Python before handing the query to Lucene. */
+int msr_search_text(msr_index* ix, const char* const* queries, int nq, int k, uint32_t flags, uint32_t* out_doc_ord,
+                    float* out_score, uint32_t* out_score_u32, int32_t* out_n);
+
 /* ---- resident batches: the same search with inputs and outputs kept in HBM (benchmark, pipelining) ---- */
 int msr_batch_create(msr_index* ix, const int64_t* q_ptr, const int32_t* q_term, const int32_t* q_w, int nq,
                      int kmax, uint32_t flags, msr_batch** out);

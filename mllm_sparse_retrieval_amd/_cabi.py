@@ -56,6 +56,7 @@ SYMBOLS = [
     ("msr_term_str", _I, [_VP, _U32, C.POINTER(_CP)]),
     ("msr_docid_str", _I, [_VP, _U32, C.POINTER(_CP)]),
     ("msr_search_csr", _I, [_VP, _VP, _VP, _VP, _I, _I, _U32, _VP, _VP, _VP, _VP]),
+    ("msr_search_text", _I, [_VP, _VP, _I, _I, _U32, _VP, _VP, _VP, _VP]),
     ("msr_batch_create", _I, [_VP, _VP, _VP, _VP, _I, _I, _U32, C.POINTER(_VP)]),
     ("msr_batch_search", _I, [_VP, _I]),
     ("msr_batch_sync", _I, [_VP]),

@@ -20,6 +20,7 @@
 #include <algorithm>
 #include <atomic>
 #include <cerrno>
+#include <climits>
 #include <cmath>
 #include <cstring>
 #include <memory>
@@ -1247,6 +1248,63 @@ int msr_term_str(const msr_index* ix, uint32_t term_id, const char** s) {
     }
     *s = ix->host.term_str + ix->host.term_off[term_id];
     return MSR_OK;
+}
+
+// Query strings as the reference builds them (every token repeated `weight` times, src/search.py:419-422) -> CSR of
+// (term id, count): whitespace split, token-frequency count, dictionary lookup (out-of-vocabulary tokens dropped), all
+// in one pass on the host. This is the half of pyserini's batch_search that runs before Lucene.
+static void encode_query_strings(const msr_index* ix, const char* const* queries, int nq, std::vector<int64_t>& q_ptr,
+                                 std::vector<int32_t>& q_term, std::vector<int32_t>& q_w) {
+    q_ptr.assign((size_t)nq + 1, 0);
+    q_term.clear();
+    q_w.clear();
+    std::unordered_map<std::string, int32_t> slot;  // token -> index into q_term/q_w of the current query
+    std::string tok;
+    for (int i = 0; i < nq; ++i) {
+        slot.clear();
+        const size_t first = q_term.size();
+        const char* p = queries[i] ? queries[i] : "";
+        while (*p) {
+            while (*p && is_space((unsigned char)*p)) ++p;
+            const char* b = p;
+            while (*p && !is_space((unsigned char)*p)) ++p;
+            if (p == b) break;
+            tok.assign(b, p);
+            auto it = slot.find(tok);
+            if (it != slot.end()) {
+                if (it->second >= 0 && q_w[(size_t)it->second] < INT32_MAX) q_w[(size_t)it->second]++;
+                continue;
+            }
+            const int32_t tid = ix->host.lookup(tok.c_str());
+            if (tid < 0) {
+                slot.emplace(tok, -1);  // out of vocabulary: remember, so that repeats cost one hash probe
+                continue;
+            }
+            slot.emplace(tok, (int32_t)q_term.size());
+            q_term.push_back(tid);
+            q_w.push_back(1);
+        }
+        (void)first;
+        q_ptr[(size_t)i + 1] = (int64_t)q_term.size();
+    }
+}
+
+int msr_search_text(msr_index* ix, const char* const* queries, int nq, int k, uint32_t flags, uint32_t* out_doc_ord,
+                    float* out_score, uint32_t* out_score_u32, int32_t* out_n) {
+    if (!ix || nq < 0 || (nq && !queries)) {
+        set_error("msr_search_text: bad argument");
+        return MSR_E_INVAL;
+    }
+    try {
+        std::vector<int64_t> q_ptr;
+        std::vector<int32_t> q_term, q_w;
+        encode_query_strings(ix, queries, nq, q_ptr, q_term, q_w);
+        return msr_search_csr(ix, q_ptr.data(), q_term.data(), q_w.data(), nq, k, flags, out_doc_ord, out_score, out_score_u32,
+                              out_n);
+    } catch (const std::bad_alloc&) {
+        set_error("out of host memory while encoding the queries");
+        return MSR_E_NOMEM;
+    }
 }
 
 int msr_docid_str(const msr_index* ix, uint32_t ord, const char** s) {

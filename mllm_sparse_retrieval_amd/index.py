@@ -178,6 +178,20 @@ class SparseIndex:
                                    ptr(su), ptr(n)))
         return ords, sc, su, n
 
+    def search_text(self, queries, k, drop_df_eq_n=True):
+        """Query strings (tokens repeated `weight` times, src/search.py:419-422) -> the same outputs as search_csr;
+        tokenisation, counting and dictionary lookup run in C inside the call."""
+        nq = len(queries)
+        arr, keep = _cabi.c_str_array(queries)
+        ords = np.empty((nq, k), dtype=np.uint32)
+        sc = np.empty((nq, k), dtype=np.float32)
+        su = np.empty((nq, k), dtype=np.uint32)
+        n = np.zeros(nq, dtype=np.int32)
+        flags = MSR_F_DROP_DF_EQ_N if drop_df_eq_n else 0
+        check(lib().msr_search_text(self._h, C.cast(arr, C.c_void_p), nq, int(k), flags, ptr(ords), ptr(sc), ptr(su), ptr(n)))
+        del keep
+        return ords, sc, su, n
+
     def batch(self, q_ptr, q_term, q_w, kmax, drop_df_eq_n=True, term_shard=None):
         return QueryBatch(self, q_ptr, q_term, q_w, kmax, drop_df_eq_n, term_shard)
 

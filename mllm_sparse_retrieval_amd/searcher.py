@@ -74,15 +74,17 @@ class LuceneImpactSearcher:
     def batch_search(self, queries, qids, k=10, threads=1, fields=None):
         if len(queries) != len(qids):
             raise ValueError("queries and qids differ in length")
-        q_ptr, term_ids, ws = self._encode(queries)
         # idf = log(N/df) > min_idf: with the default min_idf = 0 exactly the df == N terms go (contract T3);
-        # a positive min_idf is applied here on the host.
+        # a positive min_idf is applied here on the host (Python tokenisation), everything else tokenises in C.
         if self.min_idf > 0:
+            q_ptr, term_ids, ws = self._encode(queries)
             df = self.index.df(term_ids).astype(np.float64)
             with np.errstate(divide="ignore"):
                 idf = np.log(self.index.n_docs / np.maximum(df, 1e-300))
             ws = np.where((df > 0) & (idf > self.min_idf), ws, 0).astype(np.int32)
-        ords, scores, _, n = self.index.search_csr(q_ptr, term_ids, ws, k, drop_df_eq_n=self.min_idf >= 0)
+            ords, scores, _, n = self.index.search_csr(q_ptr, term_ids, ws, k, drop_df_eq_n=True)
+        else:
+            ords, scores, _, n = self.index.search_text(queries, k, drop_df_eq_n=self.min_idf >= 0)
         out = {}
         table = self.index.docid_table() if len(qids) * k > 64 else None
         score_rows = scores.tolist()

@@ -518,3 +518,28 @@ def test_sparsifier_against_torch(m, dtype, vocab, k):
         b = {int(i) for i, v in zip(ti[r].numpy(), tv32[r]) if v > kth + 1e-3}
         assert a == b
     assert (np.diff(vals, axis=1) <= 0).all()
+
+
+def test_text_queries_tokenised_in_c(m, tmp_path):
+    """msr_search_text (C tokenisation + counting + lookup) == Python tokenisation + msr_search_csr, on query strings
+    built like src/search.py:419-422, including OOV tokens, odd whitespace and an empty string."""
+    from mllm_sparse_retrieval_amd.searcher import tokenize_queries
+
+    docs, (qp, qt, qw) = helpers.synth(4000, 32, 60, 25, 800, seed=19)
+    terms = [f"ġt{i}" for i in range(800)]
+    path = m.build_index_from_csr(str(tmp_path / "x.idx"), *docs, 800, term_strs=terms)
+    queries = []
+    for i in range(60):
+        toks, vals = [terms[t] for t in qt[qp[i]:qp[i + 1]]], qw[qp[i]:qp[i + 1]] % 7
+        q = ""
+        for tok, v in zip(toks, vals):
+            q += (" " + tok) * int(v)
+        queries.append(q.strip())
+    queries += ["", "   ", "unicorn  ġt5\\tġt5\\n ġt7 unicorn", "ġt1"]
+    with m.SparseIndex(path, device=0) as ix:
+        got = ix.search_text(queries, 10)
+        p, toks, ws = tokenize_queries(queries)
+        want = ix.search_csr(p, ix.lookup(toks), ws, 10)
+        for a, b in zip(got, want):
+            assert (a == b).all()
+        assert got[3][60] == 0 and got[3][61] == 0 and got[3][62] > 0
