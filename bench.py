@@ -108,16 +108,18 @@ def device_sync():
         pass
 
 
-def timed_steps(batch, k, steps, warmup, ranks, sharded=False):
+def timed_steps(batch, k, steps, warmup, ranks, sharded=False, step=None):
+    """`step` (optional) replaces batch.search for exchanges that run on the host (gloo fallback)."""
+    run = step if step is not None else (lambda: batch.search(k, sharded=sharded))
     for _ in range(warmup):
-        batch.search(k, sharded=sharded)
+        run()
     batch.sync()
     batch.timing_reset()
     ranks.barrier()
     device_sync()
     t0 = time.perf_counter()
     for _ in range(steps):
-        batch.search(k, sharded=sharded)
+        run()
     batch.sync()
     device_sync()
     ranks.barrier()
@@ -293,6 +295,9 @@ def run_c4(args, ranks, m, wlmod):
             err = e
         if ranks.any_failed(err is not None):
             raise RuntimeError(f"opening the index shard failed on some rank (this rank: {err})")
+        exchange = "one RCCL all-gather of per-shard top-k + exact merge"
+        step = None
+        fallback_result = {}
         if sharded:
             uid = ranks.bcast_bytes(m.comm_unique_id() if ranks.rank == 0 else None, 128)
             try:
@@ -300,26 +305,38 @@ def run_c4(args, ranks, m, wlmod):
             except Exception as e:
                 err = e
             if ranks.any_failed(err is not None):
-                raise RuntimeError(f"RCCL communicator init failed on some rank (this rank: {err})")
+                # RCCL could not be brought up (this cannot be rehearsed on a 1-GPU box): keep the doc-range shards and
+                # move the per-shard lists through torch.distributed (gloo) instead, merged by msr_merge_lists
+                log(f"[bench r{ranks.rank}] RCCL init failed ({err}); falling back to a gloo all-gather of the lists")
+                from mllm_sparse_retrieval_amd import dist as mdist
+
+                exchange = f"FALLBACK: gloo all-gather of host lists + msr_merge_lists (RCCL init failed: {err})"
+                sharded = False  # batch.search without the in-library exchange
+
+                def step():
+                    batch.search(10)
+                    o, _, su, cnt = batch.fetch()
+                    g = mdist.all_gather_lists(ranks.dist, o, su, cnt)
+                    fallback_result["r"] = ix.merge_lists(g[0], g[1], g[2], 10)
         batch = ix.batch(qp, qt, qw, 10)
-        wall, score_ms, merge_ms = timed_steps(batch, 10, args.steps, args.warmup, ranks, sharded=sharded)
+        wall, score_ms, merge_ms = timed_steps(batch, 10, args.steps, args.warmup, ranks, sharded=sharded, step=step)
         nq = len(qp) - 1
         out = {"workload": f"synthetic {args.c4_docs} docs x128 nnz ({ix.n_postings} postings), {nq} queries x120 nnz, "
                            f"V=30000, top-10",
                "value": round(nq * args.steps / wall, 1), "unit": "queries/s", "n_gpus": ranks.world,
                "ms_per_step": round(wall / args.steps * 1e3, 3), "scaling": "strong",
-               "parallelism": "1 GPU" if not sharded else
+               "parallelism": "1 GPU" if ranks.world == 1 else
                f"index doc-range sharded over {ranks.world} GPUs ({ix.shard_ntiles} of {ix.n_tiles} tiles on rank 0), "
-               f"one RCCL all-gather of per-shard top-k + exact merge"}
+               + exchange}
         if ranks.rank == 0:
-            out["roofline"] = roofline(batch, 10, score_ms, "c4_1m" if not sharded else f"c4_1m_shard{ranks.world}")
+            out["roofline"] = roofline(batch, 10, score_ms, "c4_1m" if ranks.world == 1 else f"c4_1m_shard{ranks.world}")
             out["roofline"]["merge_and_exchange_ms"] = round(merge_ms, 4)
             if ranks.world == 1 and not args.no_cpu:
                 cb, par = cpu_baseline(wl, batch.fetch(), args.cpu_seconds, args.cpu_threads)
                 out["cpu_baseline"] = cb
                 out["parity"] = par
                 out["speedup_vs_cpu"] = round(out["value"] / cb["value"], 1)
-        doc_sharded_result = batch.fetch() if sharded else None
+        doc_sharded_result = batch.fetch() if sharded else fallback_result.get("r")
         batch.close()
         if sharded:
             ix.comm_destroy()
