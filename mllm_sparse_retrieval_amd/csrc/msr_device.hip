@@ -119,6 +119,20 @@ int device_attach(msr_index* ix, int device) {
     const uint32_t t0 = ix->shard_tile0, nt = ix->shard_ntiles;
     if (nt) {
         const uint32_t* sp = ix->host.seg_ptr + (uint64_t)t0 * stride;
+        // the kernels trust seg_ptr: a non-monotone or out-of-range table (corrupt file) must not reach the GPU
+        {
+            uint32_t prev = sp[0];
+            bool bad = false;
+            for (uint64_t i = 1; i < (uint64_t)nt * stride && !bad; ++i) {
+                bad = sp[i] < prev;
+                prev = sp[i];
+            }
+            if (bad || (uint64_t)prev > h->n_vecs) {
+                set_error("index file is corrupt: the segment table of tiles [%u, %u) is not monotone / exceeds the postings",
+                          t0, t0 + nt);
+                return fail(MSR_E_FORMAT);
+            }
+        }
         d->vec_base = sp[0];
         d->shard_vecs = (uint64_t)sp[(uint64_t)(nt - 1) * stride + h->n_terms] - d->vec_base;
         const size_t seg_bytes = (size_t)nt * stride * 4;
