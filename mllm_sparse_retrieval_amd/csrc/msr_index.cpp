@@ -449,15 +449,67 @@ int build_from_csr(const char* out_path, uint64_t n_docs, uint32_t n_terms, cons
                     postings[vec * 4 + j / nv] = (e.second << 16) | local;
                 }
             }
-            // padding: weight 0 (adds nothing) with a lane-distinct ordinal, so that the padded lanes of one LDS
-            // atomic do not pile onto one accumulator
-            for (uint32_t v = 0; v < n_terms; ++v) {
-                const uint32_t cntv = seg_cnt[v];
-                const uint32_t m = cntv % kChunkPostings;
-                if (m == 0 || m % 4 == 0) continue;
-                const uint32_t nv = (m + 3) / 4;
-                const uint64_t vec0 = (uint64_t)p[v] + (uint64_t)(cntv / kChunkPostings) * (kChunkPostings / 4);
-                for (uint32_t j = m; j < nv * 4; ++j) postings[(vec0 + j % nv) * 4 + j / nv] = j % nv;
+            // pass C: bank-aware arrangement inside every chunk. One LDS atomic of the scoring kernel adds element e of
+            // the 64 lanes' vecs; the hardware serves lanes 0-31 and 32-63 as two groups over 32 banks
+            // (bank = accumulator index mod 32), one extra cycle per additional lane on a bank. A chunk therefore
+            // consists of up to 8 groups (4 elements x 2 half-waves) and its postings are dealt to them so that a
+            // group holds as few postings per bank as possible: one from every non-empty bank first (largest bank
+            // first), repeats only when fewer than 32 banks are left. Padding slots get weight 0 and a free bank.
+            // The order of postings inside a chunk carries no meaning for the kernel.
+            {
+                std::vector<uint32_t> bucket[32];
+                std::vector<uint32_t> chunk;
+                for (uint32_t v = 0; v < n_terms; ++v) {
+                    const uint32_t cntv = seg_cnt[v];
+                    for (uint32_t c0 = 0; c0 < cntv; c0 += kChunkPostings) {
+                        const uint32_t m = std::min<uint32_t>(kChunkPostings, cntv - c0);
+                        const uint32_t nv = (m + 3) / 4;
+                        uint32_t* base = postings.data() + ((uint64_t)p[v] + (uint64_t)(c0 / kChunkPostings) * (kChunkPostings / 4)) * 4;
+                        for (auto& b : bucket) b.clear();
+                        for (uint32_t j = 0; j < m; ++j) {
+                            const uint32_t x = base[(j % nv) * 4 + j / nv];
+                            bucket[x & 31u].push_back(x);
+                        }
+                        for (uint32_t e = 0; e < 4; ++e)
+                            for (uint32_t half = 0; half < 2; ++half) {
+                                const uint32_t l0 = half * 32;
+                                if (l0 >= nv) continue;
+                                const uint32_t cap = std::min<uint32_t>(32, nv - l0);
+                                chunk.clear();
+                                uint32_t used = 0;  // banks already taken in this group
+                                while (chunk.size() < cap) {
+                                    // one pass over the banks, fullest first, taking one posting from each
+                                    uint32_t order[32];
+                                    for (uint32_t b = 0; b < 32; ++b) order[b] = b;
+                                    std::sort(order, order + 32, [&](uint32_t a2, uint32_t b2) {
+                                        return bucket[a2].size() > bucket[b2].size() || (bucket[a2].size() == bucket[b2].size() && a2 < b2);
+                                    });
+                                    bool any = false;
+                                    for (uint32_t oi = 0; oi < 32 && chunk.size() < cap; ++oi) {
+                                        auto& b = bucket[order[oi]];
+                                        if (b.empty()) break;
+                                        chunk.push_back(b.back());
+                                        b.pop_back();
+                                        used |= 1u << order[oi];
+                                        any = true;
+                                    }
+                                    if (!any) break;  // postings exhausted: the rest of the group is padding
+                                }
+                                for (uint32_t i = 0; i < cap; ++i) {
+                                    uint32_t x;
+                                    if (i < chunk.size()) {
+                                        x = chunk[i];
+                                    } else {
+                                        uint32_t b = 0;
+                                        while (b < 31 && (used >> b & 1u)) ++b;
+                                        used |= 1u << b;
+                                        x = b;  // weight 0, accumulator b
+                                    }
+                                    base[(l0 + i) * 4 + e] = x;
+                                }
+                            }
+                    }
+                }
             }
         }
     });

@@ -48,18 +48,20 @@ def index_file_to_dense(ix):
         for t in range(ix["n_terms"]):
             a, b = int(ix["seg_ptr"][tile, t]) * 4, int(ix["seg_ptr"][tile, t + 1]) * 4
             seg = ix["postings"][a:b]
-            # undo the chunk interleave (csrc/msr_internal.h): chunk of m postings over nv vecs, posting j at
-            # vec j % nv, element j / nv  ->  reading element-major gives the postings in ordinal order
+            # a segment is a run of chunks (256 postings = 64 vecs); the order of postings INSIDE a chunk is free (the
+            # builder arranges them by LDS bank, csrc/msr_index.cpp pass C), chunks follow each other in ordinal order
             real = []
+            prev_max = -1
             for c0 in range(0, len(seg), 256):
-                ch = seg[c0 : c0 + 256].reshape(-1, 4)
-                flat = ch.T.reshape(-1)
-                nz = flat[(flat >> 16) != 0]  # weight 0 = padding
-                assert (flat[: len(nz)] == nz).all(), "padding must trail the chunk"
-                real.append(nz)
+                flat = seg[c0 : c0 + 256]
+                nz = np.sort(flat[(flat >> 16) != 0] & 0xFFFF)  # weight 0 = padding
+                assert len(flat) - len(nz) <= 3 or c0 + 256 >= len(seg), "only the last chunk is partial"
+                assert len(nz) and nz[0] > prev_max, "chunks partition the segment in ordinal order"
+                prev_max = int(nz[-1])
+                real.append(flat[(flat >> 16) != 0])
             real = np.concatenate(real) if real else np.zeros(0, np.uint32)
             loc = (real & 0xFFFF).astype(np.int64)
-            assert (np.diff(loc) > 0).all(), "ordinals ascend inside a segment"
+            assert len(np.unique(loc)) == len(loc), "one posting per doc"
             D[tile * ix["tile_docs"] + loc, t] += (real >> 16).astype(np.int64)
     # dense head: slot s of pair s // 2 holds the weights of term dense_terms[s]; those terms have no segments
     for s, t in enumerate(ix["dense_terms"]):
