@@ -63,7 +63,29 @@ __device__ __forceinline__ uint32_t rdl(uint32_t v, uint32_t l) { return (uint32
 
 // Rank-by-counting over `n` UNIQUE non-zero keys in LDS: key with rank r < k goes to out[r]; slots [n, k) get 0.
 template <int NT>
-__device__ __forceinline__ void rank_and_emit(const uint64_t* cand, int n, int k, uint64_t* __restrict__ out) {
+__device__ __forceinline__ void rank_and_emit(uint64_t* cand, int n, int k, uint64_t* __restrict__ out) {
+    if (n > 256) {
+        // many keys (k in the hundreds): bitonic sort in LDS, descending, O(n log^2 n) instead of O(n^2) counting.
+        // `cand` has room for the next power of two (capacity is a power of two >= n).
+        int P = 512;
+        while (P < n) P <<= 1;
+        for (int i = n + (int)threadIdx.x; i < P; i += NT) cand[i] = 0;
+        __syncthreads();
+        for (int size = 2; size <= P; size <<= 1)
+            for (int stride = size >> 1; stride > 0; stride >>= 1) {
+                for (int i = threadIdx.x; i < P / 2; i += NT) {
+                    const int lo = 2 * i - (i & (stride - 1)), hi = lo + stride;
+                    const uint64_t x = cand[lo], y = cand[hi];
+                    if ((x < y) == ((lo & size) == 0)) {
+                        cand[lo] = y;
+                        cand[hi] = x;
+                    }
+                }
+                __syncthreads();
+            }
+        for (int i = threadIdx.x; i < k; i += NT) out[i] = i < n ? cand[i] : 0;
+        return;
+    }
     if (n <= 64) {
         // one wave, keys in registers, partner keys broadcast with v_readlane (no LDS round trips)
         if (threadIdx.x < 64) {
