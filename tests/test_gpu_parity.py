@@ -543,3 +543,8 @@ def test_text_queries_tokenised_in_c(m, tmp_path):
         for a, b in zip(got, want):
             assert (a == b).all()
         assert got[3][60] == 0 and got[3][61] == 0 and got[3][62] > 0
+
+
+def test_large_vocabulary_llama3_shape(m, tmp_path):
+    # V = 128 256 (llama-3 llava-next vocabulary): seg_ptr rows of 0.5 MB per tile
+    _case(m, tmp_path, 12000, 128, 300, 128, 128256, seed=128, tile_docs=0, ks=[10])
