@@ -177,7 +177,16 @@ def cpu_baseline(wl, got, target_seconds, threads):
     mask = np.arange(wl.k)[None, :] < w_n[:, None]
     mism = int((g_n[:n] != w_n).sum() + (g_ord[:n].astype(np.int64)[mask] != w_ord[mask]).sum()
                + (g_u32[:n].astype(np.int64)[mask] != w_sc[mask]).sum())
+    cpu_model = "unknown"
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                cpu_model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
     return {"value": round(n / dt_s, 1), "unit": "queries/s", "cores": threads, "kind": "port",
+            "cpu_model": cpu_model, "host_logical_cpus": os.cpu_count(),
             "sample": f"first {n} of {nq} queries of the same workload, {threads} threads, exhaustive term-at-a-time "
                       f"C restatement (oracle/oracle_taat.c); index build {build_s:.1f}s not timed",
             "seconds": round(dt_s, 2)}, {"checked_queries": n, "mismatches": mism}
