@@ -1314,7 +1314,6 @@ static void encode_query_strings(const msr_index* ix, const char* const* queries
     std::string tok;
     for (int i = 0; i < nq; ++i) {
         slot.clear();
-        const size_t first = q_term.size();
         const char* p = queries[i] ? queries[i] : "";
         while (*p) {
             while (*p && is_space((unsigned char)*p)) ++p;
@@ -1336,7 +1335,6 @@ static void encode_query_strings(const msr_index* ix, const char* const* queries
             q_term.push_back(tid);
             q_w.push_back(1);
         }
-        (void)first;
         q_ptr[(size_t)i + 1] = (int64_t)q_term.size();
     }
 }
