@@ -174,10 +174,11 @@ __global__ __launch_bounds__(NT, MIN_WAVES) void score_tiles(const ScoreArgs a) 
         }
         __syncthreads();
         if (tid < kQtBlock) {
-            uint32_t off = 0;
-            for (uint32_t w = 0; w < wave; ++w) off += wsum[w];
+            // (written without a loop: hipcc vectorises `for (w < wave) off += wsum[w]` into a 32-wide LDS sweep)
+            const uint32_t w0 = wsum[0], w1 = wsum[1], w2 = wsum[2], w3 = wsum[3];
+            const uint32_t off = (wave > 0 ? w0 : 0u) + (wave > 1 ? w1 : 0u) + (wave > 2 ? w2 : 0u);
             pref[tid] = nch + off;
-            if (tid == kQtBlock - 1) pref[kQtBlock] = off + wsum[wave];
+            if (tid == kQtBlock - 1) pref[kQtBlock] = w0 + w1 + w2 + w3;
         }
         __syncthreads();
         // ---- the round's chunks are dealt round-robin to the waves (chunk c -> wave c % NW), which spreads the

@@ -62,9 +62,11 @@ __device__ __forceinline__ uint32_t rfl(uint32_t v) { return (uint32_t)__builtin
 __device__ __forceinline__ uint32_t rdl(uint32_t v, uint32_t l) { return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)l); }
 
 // Rank-by-counting over `n` UNIQUE non-zero keys in LDS: key with rank r < k goes to out[r]; slots [n, k) get 0.
-template <int NT>
+// BITONIC: compile the sort path in (kernel instances for k > 512; the k <= 512 instances of score_tiles sit at the
+// 64-VGPR edge and must not carry it).
+template <int NT, bool BITONIC = true>
 __device__ __forceinline__ void rank_and_emit(uint64_t* cand, int n, int k, uint64_t* __restrict__ out) {
-    if (n > 256) {
+    if (BITONIC && n > 256) {
         // many keys (k in the hundreds): bitonic sort in LDS, descending, O(n log^2 n) instead of O(n^2) counting.
         // `cand` has room for the next power of two (capacity is a power of two >= n).
         int P = 512;
@@ -293,7 +295,7 @@ __device__ __forceinline__ void tile_select(const uint4* a4, uint64_t* cand, uin
         __syncthreads();
         n_cand = min(ss.n_cand, (uint32_t)CAND);  // == min(k, #positive) <= CAND by construction
     }
-    rank_and_emit<NT>(cand, (int)n_cand, k, out);
+    rank_and_emit<NT, (CAND > 512)>(cand, (int)n_cand, k, out);
 }
 
 
