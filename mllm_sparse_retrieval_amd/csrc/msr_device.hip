@@ -11,55 +11,56 @@
 namespace msr {
 
 // ------------------------------------------------------------------------------------------------ launch
-static int launch_score(hipStream_t st, uint32_t tile_docs, uint32_t ntiles, const ScoreArgs& a, bool dump = false) {
-    const uint64_t blocks = (uint64_t)ntiles * a.qn;
-    if (blocks == 0) return MSR_OK;
-    if (blocks > 0x7FFFFFFFull) {
-        set_error("too many workgroups (%llu tiles x queries); split the batch", (unsigned long long)blocks);
-        return MSR_E_RANGE;
-    }
-    switch (tile_docs) {
-#define MSR_LAUNCH(T, N, UU, W, WR)                                                                           \
-    if (dump)                                                                                                 \
-        hipLaunchKernelGGL((score_tiles<T, N, UU, WR, 512, false, 1>), dim3((uint32_t)blocks), dim3(N), 0, st, a); \
-    else if (a.dbg == 8u && a.k <= 512) /* stamps only: same shape as the production instance */             \
-        hipLaunchKernelGGL((score_tiles<T, N, UU, W, 512, true>), dim3((uint32_t)blocks), dim3(N), 0, st, a);   \
-    else if (a.dbg)                                                                                           \
-        hipLaunchKernelGGL((score_tiles<T, N, UU, WR, 1024, true>), dim3((uint32_t)blocks), dim3(N), 0, st, a); \
-    else if (a.k <= 512)                                                                                      \
-        hipLaunchKernelGGL((score_tiles<T, N, UU, W, 512, false>), dim3((uint32_t)blocks), dim3(N), 0, st, a);  \
-    else                                                                                                      \
-        hipLaunchKernelGGL((score_tiles<T, N, UU, WR, 1024, false>), dim3((uint32_t)blocks), dim3(N), 0, st, a); \
+static int launch_score(hipStream_t st, uint32_t tile_docs, uint32_t ntiles, const ScoreArgs& a0, bool dump = false) {
+    if (ntiles == 0 || a0.qn == 0) return MSR_OK;
+    // grid = (queries, tiles): x runs fastest in dispatch order, so the workgroups in flight share a tile
+    for (uint32_t tl0 = 0; tl0 < ntiles; tl0 += kMaxGridY) {
+        ScoreArgs a = a0;
+        a.tl0 = tl0;
+        const dim3 grid(a.qn, std::min<uint32_t>(kMaxGridY, ntiles - tl0));
+        switch (tile_docs) {
+#define MSR_LAUNCH(T, N, UU, W, WR)                                                                \
+    if (dump)                                                                                      \
+        hipLaunchKernelGGL((score_tiles<T, N, UU, WR, 512, false, 1>), grid, dim3(N), 0, st, a);   \
+    else if (a.dbg == 8u && a.k <= 512) /* stamps only: same shape as the production instance */  \
+        hipLaunchKernelGGL((score_tiles<T, N, UU, W, 512, true>), grid, dim3(N), 0, st, a);        \
+    else if (a.dbg)                                                                                \
+        hipLaunchKernelGGL((score_tiles<T, N, UU, WR, 1024, true>), grid, dim3(N), 0, st, a);      \
+    else if (a.k <= 512)                                                                           \
+        hipLaunchKernelGGL((score_tiles<T, N, UU, W, 512, false>), grid, dim3(N), 0, st, a);       \
+    else                                                                                           \
+        hipLaunchKernelGGL((score_tiles<T, N, UU, WR, 1024, false>), grid, dim3(N), 0, st, a);     \
     break;
-        // <tile, threads, chunk loads per bank, min waves/SIMD of the k <= 512 instance, of the other instances>
-        // LDS per workgroup = 4 B x tile + 4-8 KiB candidates + maxima -> workgroups (waves) per CU:
-        case 32768: MSR_LAUNCH(32768, 1024, 8, 4, 4)  // 1 (16)
-        case 16384: MSR_LAUNCH(16384, 512, 8, 4, 4)   // 2 (16)
-        case 12288: MSR_LAUNCH(12288, 512, 4, 4, 4)   // 2 (16)
-        case 8192: MSR_LAUNCH(8192, 512, 4, 8, 6)     // 4 (32) with k <= 512, 3 (24) above
-        case 4096: MSR_LAUNCH(4096, 256, 4, 6, 5)     // 7 (28)
+            // <tile, threads, chunk loads per bank, min waves/SIMD of the k <= 512 instance, of the other instances>
+            // LDS per workgroup = 4 B x tile + 4-8 KiB candidates + maxima -> workgroups (waves) per CU:
+            case 32768: MSR_LAUNCH(32768, 1024, 8, 4, 4)  // 1 (16)
+            case 16384: MSR_LAUNCH(16384, 512, 8, 4, 4)   // 2 (16)
+            case 12288: MSR_LAUNCH(12288, 512, 4, 4, 4)   // 2 (16)
+            case 8192: MSR_LAUNCH(8192, 512, 4, 8, 6)     // 4 (32) with k <= 512, 3 (24) above
+            case 4096: MSR_LAUNCH(4096, 256, 4, 6, 5)     // 7 (28)
 #undef MSR_LAUNCH
-        default:
-            set_error("no kernel instance for tile_docs=%u (supported: 4096, 8192, 12288, 16384, 32768)", tile_docs);
-            return MSR_E_RANGE;
+            default:
+                set_error("no kernel instance for tile_docs=%u (supported: 4096, 8192, 12288, 16384, 32768)", tile_docs);
+                return MSR_E_RANGE;
+        }
+        HIP_TRY(hipGetLastError());
     }
-    HIP_TRY(hipGetLastError());
     return MSR_OK;
 }
 
 int launch_select(hipStream_t st, uint32_t tile_docs, const SelectArgs& a) {
-    const uint64_t blocks = (uint64_t)a.tpr * a.qn;
-    if (blocks == 0) return MSR_OK;
-    if (blocks > 0x7FFFFFFFull) {
-        set_error("too many workgroups in select_tiles");
+    if (a.tpr == 0 || a.qn == 0) return MSR_OK;
+    if (a.tpr > kMaxGridY) {
+        set_error("select_tiles: %u tiles per rank exceed the grid limit of %u", a.tpr, kMaxGridY);
         return MSR_E_RANGE;
     }
+    const dim3 grid(a.qn, a.tpr);  // x = query, y = tile of the rank's range
     switch (tile_docs) {
-        case 32768: hipLaunchKernelGGL((select_tiles<32768, 1024, 1024>), dim3((uint32_t)blocks), dim3(1024), 0, st, a); break;
-        case 16384: hipLaunchKernelGGL((select_tiles<16384, 512, 1024>), dim3((uint32_t)blocks), dim3(512), 0, st, a); break;
-        case 12288: hipLaunchKernelGGL((select_tiles<12288, 512, 1024>), dim3((uint32_t)blocks), dim3(512), 0, st, a); break;
-        case 8192: hipLaunchKernelGGL((select_tiles<8192, 512, 1024>), dim3((uint32_t)blocks), dim3(512), 0, st, a); break;
-        case 4096: hipLaunchKernelGGL((select_tiles<4096, 256, 1024>), dim3((uint32_t)blocks), dim3(256), 0, st, a); break;
+        case 32768: hipLaunchKernelGGL((select_tiles<32768, 1024, 1024>), grid, dim3(1024), 0, st, a); break;
+        case 16384: hipLaunchKernelGGL((select_tiles<16384, 512, 1024>), grid, dim3(512), 0, st, a); break;
+        case 12288: hipLaunchKernelGGL((select_tiles<12288, 512, 1024>), grid, dim3(512), 0, st, a); break;
+        case 8192: hipLaunchKernelGGL((select_tiles<8192, 512, 1024>), grid, dim3(512), 0, st, a); break;
+        case 4096: hipLaunchKernelGGL((select_tiles<4096, 256, 1024>), grid, dim3(256), 0, st, a); break;
         default:
             set_error("no kernel instance for tile_docs=%u", tile_docs);
             return MSR_E_RANGE;

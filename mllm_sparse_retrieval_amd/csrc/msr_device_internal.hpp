@@ -27,6 +27,7 @@ namespace msr {
 // ------------------------------------------------------------------------------------------------ constants
 constexpr int kQtBlock = 256;    // query terms staged in LDS per round
 constexpr int kCandCap = 1024;   // candidate keys per workgroup (>= MSR_KMAX)
+constexpr uint32_t kMaxGridY = 65535;  // HIP grid limit in y (tiles per launch)
 constexpr int kChunkVecs = 64;   // one chunk = one wave-wide uint4 load = 256 postings = 1 KiB
 static_assert(kCandCap >= MSR_KMAX, "candidate buffer must hold k keys");
 
@@ -108,6 +109,7 @@ struct ScoreArgs {
     uint32_t vec_base;
     uint32_t n_terms;
     uint32_t tile0;            // first (global) tile of the shard
+    uint32_t tl0;              // first shard-local tile of this launch (grid y is limited to 65535 tiles)
     uint32_t nq;               // queries of the batch (row stride of `part`)
     uint32_t q0;               // this launch scores queries [q0, q0 + qn)
     uint32_t qn;

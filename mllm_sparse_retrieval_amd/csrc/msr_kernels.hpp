@@ -57,8 +57,10 @@ __global__ __launch_bounds__(NT, MIN_WAVES) void score_tiles(const ScoreArgs a) 
     };
     stamp(-1);
     if (DBG && (a.dbg & 128u)) return;  // ablation: workgroup launch cost only
-    const uint32_t tile_l = blockIdx.x / a.qn;  // tile-major: neighbours in dispatch order share the tile
-    const uint32_t q = a.q0 + blockIdx.x % a.qn;
+    // 2-D grid (x = query, y = tile): x runs fastest in dispatch order, so neighbours share the tile (tile-major)
+    // without a division in every wave's prologue
+    const uint32_t tile_l = a.tl0 + blockIdx.y;
+    const uint32_t q = a.q0 + blockIdx.x;
     const uint32_t tile_g = a.tile0 + tile_l;
     const uint64_t doc0 = (uint64_t)tile_g * TILE_DOCS;
     const uint32_t ndocs_tile = (uint32_t)min((uint64_t)TILE_DOCS, a.n_docs - doc0);
@@ -68,7 +70,11 @@ __global__ __launch_bounds__(NT, MIN_WAVES) void score_tiles(const ScoreArgs a) 
 
     const uint32_t qb = a.q_ptr[q], qe = a.q_ptr[q + 1];
     const uint32_t* seg_row = a.seg_ptr + (uint64_t)tile_l * (a.n_terms + 1);
-    const uint4* post4 = reinterpret_cast<const uint4*>(a.postings);
+    // Postings are addressed as (tile base in SGPRs) + (32-bit byte offset in a VGPR): a tile's segments span less
+    // than 4 GiB (checked when the index is attached), and the saddr form of global_load needs no 64-bit scalar
+    // address arithmetic per chunk — the scalar ALU is shared by the CU's 32 waves and is the busiest unit here.
+    const uint32_t tile_first = seg_row[0];
+    const char* const ptile = reinterpret_cast<const char*>(a.postings) + (uint64_t)(tile_first - a.vec_base) * 16u;
 
     // ---- first round's (term -> segment) lookups: two dependent global loads, issued before the zeroing so that
     // their latency hides behind it
@@ -89,17 +95,22 @@ __global__ __launch_bounds__(NT, MIN_WAVES) void score_tiles(const ScoreArgs a) 
         typedef unsigned short us2 __attribute__((ext_vector_type(2)));
         constexpr int RG = 4;  // rounds per register group
         const uint32_t qv = lane < a.n_pairs ? a.q_dense[(uint64_t)q * a.n_pairs + lane] : 0u;
-        const unsigned long long pmask = (DBG && (a.dbg & 16u)) ? 0ull : __ballot(qv != 0);
-        const uint4* dblk = reinterpret_cast<const uint4*>(a.dense) + (uint64_t)tile_l * a.n_pairs * (TILE_DOCS / 4);
+        const uint32_t pmask = (DBG && (a.dbg & 16u)) ? 0u : (uint32_t)__ballot(qv != 0);  // n_pairs <= 16
+        const char* const dbase =
+            reinterpret_cast<const char*>(a.dense) + (uint64_t)tile_l * a.n_pairs * (TILE_DOCS * 4u);
         for (int r0 = 0; r0 < rounds; r0 += RG) {
             uint4 sacc[RG];
 #pragma unroll
             for (int i = 0; i < RG; ++i) sacc[i] = make_uint4(0, 0, 0, 0);
             if (pmask) {
-                auto load_rows = [&](uint4 (&x)[RG], uint32_t p) {
+                uint32_t voff[RG];  // byte offset of this thread's vec in a pair's row, per round of the group
 #pragma unroll
-                    for (int i = 0; i < RG; ++i)  // rows past `rounds` re-read the last real round (result unused)
-                        x[i] = dblk[(uint64_t)p * (TILE_DOCS / 4) + (uint32_t)min(r0 + i, rounds - 1) * NT + tid];
+                for (int i = 0; i < RG; ++i)  // rows past `rounds` re-read the last real round (result unused)
+                    voff[i] = ((uint32_t)min(r0 + i, rounds - 1) * NT + tid) * 16u;
+                auto load_rows = [&](uint4 (&x)[RG], uint32_t p) {
+                    const char* const row = dbase + p * (uint32_t)(TILE_DOCS * 4);
+#pragma unroll
+                    for (int i = 0; i < RG; ++i) x[i] = *reinterpret_cast<const uint4*>(row + voff[i]);
                 };
                 auto add_rows = [&](const uint4 (&x)[RG], uint32_t qp) {
                     const us2 qq = __builtin_bit_cast(us2, qp);
@@ -111,15 +122,15 @@ __global__ __launch_bounds__(NT, MIN_WAVES) void score_tiles(const ScoreArgs a) 
                         sacc[i].w = __builtin_amdgcn_udot2(__builtin_bit_cast(us2, x[i].w), qq, sacc[i].w, false);
                     }
                 };
-                unsigned long long m = pmask;
+                uint32_t m = pmask;
                 uint4 xa[RG], xb[RG];
-                uint32_t pa = (uint32_t)__builtin_ctzll(m), pb = 0;
+                uint32_t pa = (uint32_t)__builtin_ctz(m), pb = 0;
                 m &= m - 1;
                 load_rows(xa, pa);
                 for (;;) {
                     const bool more_b = m != 0;
                     if (more_b) {
-                        pb = (uint32_t)__builtin_ctzll(m);
+                        pb = (uint32_t)__builtin_ctz(m);
                         m &= m - 1;
                         load_rows(xb, pb);
                     }
@@ -127,7 +138,7 @@ __global__ __launch_bounds__(NT, MIN_WAVES) void score_tiles(const ScoreArgs a) 
                     if (!more_b) break;
                     const bool more_a = m != 0;
                     if (more_a) {
-                        pa = (uint32_t)__builtin_ctzll(m);
+                        pa = (uint32_t)__builtin_ctz(m);
                         m &= m - 1;
                         load_rows(xa, pa);
                     }
@@ -163,7 +174,7 @@ __global__ __launch_bounds__(NT, MIN_WAVES) void score_tiles(const ScoreArgs a) 
                     s1 = seg_row[t + 1];
                     w = a.q_w[base + tid];
                 }
-                seg_start[tid] = s0 - a.vec_base;
+                seg_start[tid] = s0 - tile_first;  // vec index inside the tile
                 seg_len[tid] = s1 - s0;
                 seg_w[tid] = w;
                 nch = (s1 - s0 + kChunkVecs - 1) / kChunkVecs;
@@ -191,22 +202,20 @@ __global__ __launch_bounds__(NT, MIN_WAVES) void score_tiles(const ScoreArgs a) 
         const uint32_t c_end = total > wave ? (total - wave + NW - 1) / NW : 0u;  // chunks of this wave
         for (uint32_t cb = 0; cb < c_end; cb += 64) {
             const uint32_t my_i = cb + lane;
-            uint32_t m_base = 0, m_n = 0, m_w = 0;
-            if (my_i < c_end) {
-                const uint32_t my_c = wave + my_i * NW;
-                uint32_t lo = 0, hi = cnt;  // largest lo with pref[lo] <= my_c
-                while (hi - lo > 1) {
-                    const uint32_t mid = (lo + hi) >> 1;
-                    if (pref[mid] <= my_c)
-                        lo = mid;
-                    else
-                        hi = mid;
-                }
-                const uint32_t voff = (my_c - pref[lo]) * kChunkVecs;
-                m_base = seg_start[lo] + voff;
-                m_n = min((uint32_t)kChunkVecs, seg_len[lo] - voff);
-                m_w = seg_w[lo];
+            // Branch-free lower-bound search, the same (wave-uniform) number of steps in every lane: largest lo with
+            // pref[lo] <= my_c. Entries past `cnt` hold the round's total (> every chunk index), and lanes past c_end
+            // search for a chunk that does not exist — their reads stay inside pref[] and their m_n is forced to 0.
+            const uint32_t my_c = wave + my_i * NW;
+            uint32_t lo = 0;
+            for (uint32_t step = kQtBlock >> 1; step > 0; step >>= 1) {
+                if (step >= cnt) continue;  // wave-uniform: lo + step >= cnt can never be taken
+                const uint32_t mid = lo + step;
+                lo = pref[mid] <= my_c ? mid : lo;
             }
+            const uint32_t voff = (my_c - pref[lo]) * kChunkVecs;
+            const uint32_t m_base = my_i < c_end ? seg_start[lo] + voff : 0u;  // idle slots re-read the tile's first vec
+            const uint32_t m_n = my_i < c_end ? min((uint32_t)kChunkVecs, seg_len[lo] - voff) : 0u;
+            const uint32_t m_w = seg_w[lo];
             stamp(7);  // lane-parallel chunk resolution (binary search)
             if (DBG && (a.dbg & 256u)) break;  // ablation: stop after the first chunk resolution
             const uint32_t nchunk = min(64u, c_end - cb);
@@ -217,7 +226,7 @@ __global__ __launch_bounds__(NT, MIN_WAVES) void score_tiles(const ScoreArgs a) 
             auto load_bank = [&](uint4 (&v)[U], uint32_t u0) {
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
-                    const uint32_t idx = (u0 + u) & 63u;
+                    const uint32_t idx = u0 + u;  // < 64: u0 + U <= nchunk rounded up to a multiple of U
                     const uint32_t b = rdl(m_base, idx);
                     const uint32_t n = rdl(m_n, idx);
                     if (DBG && (a.dbg & 2u)) {  // ablation: no global loads, synthetic postings
@@ -225,7 +234,7 @@ __global__ __launch_bounds__(NT, MIN_WAVES) void score_tiles(const ScoreArgs a) 
                         v[u] = make_uint4((1u << 16) | (hsh >> 17), (1u << 16) | ((hsh * 31u) >> 17),
                                           (1u << 16) | ((hsh * 131u) >> 17), (1u << 16) | ((hsh * 1031u) >> 17));
                     } else {
-                        v[u] = post4[b + (lane < n ? lane : 0u)];
+                        v[u] = *reinterpret_cast<const uint4*>(ptile + ((b + (lane < n ? lane : 0u)) << 4));
                     }
                 }
             };
@@ -233,8 +242,8 @@ __global__ __launch_bounds__(NT, MIN_WAVES) void score_tiles(const ScoreArgs a) 
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
                     const uint32_t idx = u0 + u;
-                    const uint32_t n = idx < nchunk ? rdl(m_n, idx & 63u) : 0u;
-                    const uint32_t w = rdl(m_w, idx & 63u);
+                    const uint32_t n = rdl(m_n, idx);  // 0 in the slots past nchunk
+                    const uint32_t w = rdl(m_w, idx);
                     // lanes past the chunk's last vec must not touch LDS (64 lanes adding to one accumulator would
                     // serialise); padding INSIDE a vec has weight 0 and a lane-distinct ordinal
                     if (lane < n) {
@@ -310,7 +319,7 @@ __global__ __launch_bounds__(NT) void select_tiles(const SelectArgs a) {
     uint32_t* const wmax = tmax + NT;
     SelectScratch& ss = *reinterpret_cast<SelectScratch*>(un + L::kUnion + L::kTmax);
     const uint32_t tid = threadIdx.x;
-    const uint32_t t = blockIdx.x / a.qn, qi = blockIdx.x % a.qn;
+    const uint32_t t = blockIdx.y, qi = blockIdx.x;
     const uint32_t tile_g = a.rank * a.tpr + t;
     uint64_t* out = a.part + ((uint64_t)t * a.nq + a.q0 + qi) * a.k;
     if (tile_g >= a.n_tiles) {  // padding tile of the last rank

@@ -163,9 +163,9 @@ __device__ __forceinline__ void tile_select(const uint4* a4, uint64_t* cand, uin
         mymax = max(max(mymax, max(x.x, x.y)), max(x.z, x.w));
     }
     // ---- tau0: a lower bound with at least k accumulators at or above it = the k-th largest GROUP maximum.
-    //   k <= 64 : 64 groups of NT/64 consecutive threads (log2(NT/64) shuffle steps), then every wave bisects the
-    //             64 group maxima with ballots (no further barrier);
-    //   k >  64 : groups are single threads (NT maxima, NT/64 per lane of wave 0), one more barrier.
+    //   k <= 64 : 64 groups of NT/64 consecutive threads (DPP reductions), wave 0 bisects the 64 group maxima with
+    //             ballots;
+    //   k >  64 : groups are single threads (NT maxima, NT/64 per lane of wave 0).
     constexpr int G = NT / 64;  // threads per group
     static_assert(G == 4 || G == 8 || G == 16, "group maxima use the 4/8/16-lane DPP reductions");
     const uint32_t gm = group_max_u32<G>(mymax);
@@ -181,32 +181,38 @@ __device__ __forceinline__ void tile_select(const uint4* a4, uint64_t* cand, uin
             for (int i = tid; i < k; i += NT) out[i] = 0;
             return;
         }
-        if (k <= 64) {
-            uint32_t tau = 0;
-            for (int bit = 31 - __clz(smax); bit >= 0; --bit) {
-                const uint32_t t2 = tau | (1u << bit);
-                if (__popcll(__ballot(v >= t2)) >= k) tau = t2;
-            }
-            tau0 = max(tau, 1u);
-        }
-    }
-    if (k > 64 && k <= NT) {
-        if (wave == 0) {
-            uint32_t mine[NW];
+        if (k <= NT) {
+            // Wave 0 bisects for all: a ballot step is ~8 scalar instructions, and the scalar ALU is shared by the
+            // CU's 32 waves (eight waves repeating the search cost more than the extra barrier). The bisection stops
+            // after kTauBits significant bits: tau0 is then a slightly lower bound (a few more candidates), still
+            // with at least k accumulators at or above it.
+            constexpr int kTauBits = 12;
+            if (wave == 0) {
+                const int top = 31 - __clz(smax);
+                const int low = max(top - (kTauBits - 1), 0);
+                uint32_t tau = 0;
+                if (k <= 64) {
+                    for (int bit = top; bit >= low; --bit) {
+                        const uint32_t t2 = tau | (1u << bit);
+                        if (__popcll(__ballot(v >= t2)) >= k) tau = t2;
+                    }
+                } else {
+                    uint32_t mine[NW];
 #pragma unroll
-            for (int i = 0; i < NW; ++i) mine[i] = tmax[i * 64 + lane];
-            uint32_t tau = 0;
-            for (int bit = 31 - __clz(smax); bit >= 0; --bit) {
-                const uint32_t t2 = tau | (1u << bit);
-                uint32_t c = 0;
+                    for (int i = 0; i < NW; ++i) mine[i] = tmax[i * 64 + lane];
+                    for (int bit = top; bit >= low; --bit) {
+                        const uint32_t t2 = tau | (1u << bit);
+                        uint32_t c = 0;
 #pragma unroll
-                for (int i = 0; i < NW; ++i) c += (uint32_t)__popcll(__ballot(mine[i] >= t2));
-                if (c >= (uint32_t)k) tau = t2;
+                        for (int i = 0; i < NW; ++i) c += (uint32_t)__popcll(__ballot(mine[i] >= t2));
+                        if (c >= (uint32_t)k) tau = t2;
+                    }
+                }
+                if (lane == 0) ss.tau0 = max(tau, 1u);
             }
-            if (lane == 0) ss.tau0 = max(tau, 1u);
+            __syncthreads();
+            tau0 = ss.tau0;
         }
-        __syncthreads();
-        tau0 = ss.tau0;
     }
 
     stamp(4);  // thread / wave maxima, tau0
