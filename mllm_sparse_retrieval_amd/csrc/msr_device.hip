@@ -133,6 +133,15 @@ int device_attach(msr_index* ix, int device) {
                           t0, t0 + nt);
                 return fail(MSR_E_FORMAT);
             }
+            // score_tiles addresses a tile's postings with 32-bit byte offsets from the tile's first vec
+            for (uint32_t t = 0; t < nt; ++t) {
+                const uint64_t span = (uint64_t)sp[(uint64_t)t * stride + h->n_terms] - sp[(uint64_t)t * stride];
+                if (span >= (1ull << 28)) {
+                    set_error("tile %u holds %llu posting vecs (>= 2^28): build the index with a smaller tile_docs",
+                              t0 + t, (unsigned long long)span);
+                    return fail(MSR_E_RANGE);
+                }
+            }
         }
         d->vec_base = sp[0];
         d->shard_vecs = (uint64_t)sp[(uint64_t)(nt - 1) * stride + h->n_terms] - d->vec_base;

@@ -369,7 +369,7 @@ __global__ __launch_bounds__(NT) void fuse_tiles(const FuseArgs a) {
     for (int i = tid; i < rounds * 4 * NT; i += NT) acc[i] = member[i] ? f32_to_key(facc[i]) : 0u;
     __syncthreads();
     tile_select<TILE_DOCS, NT, CAND>(reinterpret_cast<const uint4*>(lds), cand, tmax, wmax, ss, rounds, doc0, (int)a.k,
-                                     a.part + ((uint64_t)tile * a.nq + q) * a.k, [](int) {});
+                                     a.part + ((uint64_t)tile * a.nq + q) * a.k, [](int) {}, threadIdx.x);
 }
 
 }  // namespace msr

@@ -70,11 +70,14 @@ __global__ __launch_bounds__(NT, MIN_WAVES) void score_tiles(const ScoreArgs a) 
 
     const uint32_t qb = a.q_ptr[q], qe = a.q_ptr[q + 1];
     const uint32_t* seg_row = a.seg_ptr + (uint64_t)tile_l * (a.n_terms + 1);
-    // Postings are addressed as (tile base in SGPRs) + (32-bit byte offset in a VGPR): a tile's segments span less
-    // than 4 GiB (checked when the index is attached), and the saddr form of global_load needs no 64-bit scalar
-    // address arithmetic per chunk — the scalar ALU is shared by the CU's 32 waves and is the busiest unit here.
+    // Postings and dense rows are read with buffer loads: (tile base + size in SGPRs) + (32-bit byte offset per
+    // lane). A tile's segments span less than 4 GiB (checked when the index is attached); there is no 64-bit address
+    // arithmetic per chunk (the scalar ALU is shared by the CU's 32 waves), no zero-extended offset pairs in VGPRs,
+    // and a read past the tile's postings returns 0 instead of faulting.
     const uint32_t tile_first = seg_row[0];
-    const char* const ptile = reinterpret_cast<const char*>(a.postings) + (uint64_t)(tile_first - a.vec_base) * 16u;
+    const __amdgpu_buffer_rsrc_t rs_post =
+        make_rsrc(reinterpret_cast<const char*>(a.postings) + (uint64_t)(tile_first - a.vec_base) * 16u,
+                  (seg_row[a.n_terms] - tile_first) * 16u);
 
     // ---- first round's (term -> segment) lookups: two dependent global loads, issued before the zeroing so that
     // their latency hides behind it
@@ -96,8 +99,9 @@ __global__ __launch_bounds__(NT, MIN_WAVES) void score_tiles(const ScoreArgs a) 
         constexpr int RG = 4;  // rounds per register group
         const uint32_t qv = lane < a.n_pairs ? a.q_dense[(uint64_t)q * a.n_pairs + lane] : 0u;
         const uint32_t pmask = (DBG && (a.dbg & 16u)) ? 0u : (uint32_t)__ballot(qv != 0);  // n_pairs <= 16
-        const char* const dbase =
-            reinterpret_cast<const char*>(a.dense) + (uint64_t)tile_l * a.n_pairs * (TILE_DOCS * 4u);
+        const __amdgpu_buffer_rsrc_t rs_dense =
+            make_rsrc(reinterpret_cast<const char*>(a.dense) + (uint64_t)tile_l * a.n_pairs * (TILE_DOCS * 4u),
+                      a.n_pairs * (uint32_t)(TILE_DOCS * 4));
         for (int r0 = 0; r0 < rounds; r0 += RG) {
             uint4 sacc[RG];
 #pragma unroll
@@ -108,9 +112,8 @@ __global__ __launch_bounds__(NT, MIN_WAVES) void score_tiles(const ScoreArgs a) 
                 for (int i = 0; i < RG; ++i)  // rows past `rounds` re-read the last real round (result unused)
                     voff[i] = ((uint32_t)min(r0 + i, rounds - 1) * NT + tid) * 16u;
                 auto load_rows = [&](uint4 (&x)[RG], uint32_t p) {
-                    const char* const row = dbase + p * (uint32_t)(TILE_DOCS * 4);
 #pragma unroll
-                    for (int i = 0; i < RG; ++i) x[i] = *reinterpret_cast<const uint4*>(row + voff[i]);
+                    for (int i = 0; i < RG; ++i) x[i] = buf_load16(rs_dense, voff[i], p * (uint32_t)(TILE_DOCS * 4));
                 };
                 auto add_rows = [&](const uint4 (&x)[RG], uint32_t qp) {
                     const us2 qq = __builtin_bit_cast(us2, qp);
@@ -123,7 +126,8 @@ __global__ __launch_bounds__(NT, MIN_WAVES) void score_tiles(const ScoreArgs a) 
                     }
                 };
                 uint32_t m = pmask;
-                uint4 xa[RG], xb[RG];
+                uint4 xa[RG] = {}, xb[RG] = {};  // (defined on every path: an undefined value at the top of a loop
+                                                 // body is folded into "the previous iteration's value" and stays live)
                 uint32_t pa = (uint32_t)__builtin_ctz(m), pb = 0;
                 m &= m - 1;
                 load_rows(xa, pa);
@@ -234,7 +238,7 @@ __global__ __launch_bounds__(NT, MIN_WAVES) void score_tiles(const ScoreArgs a) 
                         v[u] = make_uint4((1u << 16) | (hsh >> 17), (1u << 16) | ((hsh * 31u) >> 17),
                                           (1u << 16) | ((hsh * 131u) >> 17), (1u << 16) | ((hsh * 1031u) >> 17));
                     } else {
-                        v[u] = *reinterpret_cast<const uint4*>(ptile + ((b + (lane < n ? lane : 0u)) << 4));
+                        v[u] = buf_load16(rs_post, (b + (lane < n ? lane : 0u)) << 4, 0u);
                     }
                 }
             };
@@ -259,7 +263,7 @@ __global__ __launch_bounds__(NT, MIN_WAVES) void score_tiles(const ScoreArgs a) 
                     }
                 }
             };
-            uint4 va[U], vb[U];
+            uint4 va[U] = {}, vb[U] = {};  // (as xa / xb)
             load_bank(va, 0);
             for (uint32_t u0 = 0; u0 < nchunk; u0 += 2 * U) {
                 const bool more = u0 + U < nchunk;  // wave-uniform
@@ -299,7 +303,7 @@ __global__ __launch_bounds__(NT, MIN_WAVES) void score_tiles(const ScoreArgs a) 
         return;
     }
 
-    tile_select<TILE_DOCS, NT, CAND>(a4, cand, tmax, wmax, ss, rounds, doc0, k, out, stamp);
+    tile_select<TILE_DOCS, NT, CAND>(a4, cand, tmax, wmax, ss, rounds, doc0, k, out, stamp, tid);
     stamp(6);  // ranking + output
 }
 
@@ -338,7 +342,7 @@ __global__ __launch_bounds__(NT) void select_tiles(const SelectArgs a) {
         ss.smax = 0;
     }
     __syncthreads();
-    tile_select<TILE_DOCS, NT, CAND>(a4, cand, tmax, wmax, ss, rounds, doc0, (int)a.k, out, [](int) {});
+    tile_select<TILE_DOCS, NT, CAND>(a4, cand, tmax, wmax, ss, rounds, doc0, (int)a.k, out, [](int) {}, tid);
 }
 
 // ------------------------------------------------------------------------------------------------ kernel 2
@@ -425,7 +429,7 @@ __global__ __launch_bounds__(NT) void merge_lists(const MergeArgs a) {
         if (got > kCandCap) got = collect(bisect_kth(n_items, key_at));  // exactly min(k, #keys) <= kCandCap survive
         n_cand = min(got, (uint32_t)kCandCap);
     }
-    rank_and_emit<NT>(cand, (int)n_cand, k, res);
+    rank_and_emit<NT>(cand, (int)n_cand, k, res, tid);
     __syncthreads();
     const int n_hit = min((int)n_cand, k);
     for (int i = tid; i < k; i += NT) {

@@ -58,6 +58,18 @@ __device__ __forceinline__ uint64_t wave_max_u64(uint64_t v) {
     return v;
 }
 
+// Buffer loads: a 128-bit resource (base, size) in SGPRs + a 32-bit byte offset per lane + a scalar byte offset. No
+// 64-bit address arithmetic in VGPRs (the compiler otherwise keeps zero-extended offset PAIRS alive), and a read past
+// `bytes` returns 0 instead of faulting. Word 3 = 0x00020000: raw 32-bit dwords on gfx9-family targets (gfx950).
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, uint32_t bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ uint4 buf_load16(__amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t soff) {
+    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, 0);
+    return make_uint4(v.x, v.y, v.z, v.w);
+}
+
 __device__ __forceinline__ uint32_t rfl(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
 __device__ __forceinline__ uint32_t rdl(uint32_t v, uint32_t l) { return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)l); }
 
@@ -65,17 +77,19 @@ __device__ __forceinline__ uint32_t rdl(uint32_t v, uint32_t l) { return (uint32
 // BITONIC: compile the sort path in (kernel instances for k > 512; the k <= 512 instances of score_tiles sit at the
 // 64-VGPR edge and must not carry it).
 template <int NT, bool BITONIC = true>
-__device__ __forceinline__ void rank_and_emit(uint64_t* cand, int n, int k, uint64_t* __restrict__ out) {
+__device__ __forceinline__ void rank_and_emit(uint64_t* cand, int n, int k, uint64_t* __restrict__ out,
+                                              const uint32_t tid_) {
+    const int tidx = (int)tid_;  // (a parameter, so that a caller's per-iteration copy of the thread id is used)
     if (BITONIC && n > 256) {
         // many keys (k in the hundreds): bitonic sort in LDS, descending, O(n log^2 n) instead of O(n^2) counting.
         // `cand` has room for the next power of two (capacity is a power of two >= n).
         int P = 512;
         while (P < n) P <<= 1;
-        for (int i = n + (int)threadIdx.x; i < P; i += NT) cand[i] = 0;
+        for (int i = n + tidx; i < P; i += NT) cand[i] = 0;
         __syncthreads();
         for (int size = 2; size <= P; size <<= 1)
             for (int stride = size >> 1; stride > 0; stride >>= 1) {
-                for (int i = threadIdx.x; i < P / 2; i += NT) {
+                for (int i = tidx; i < P / 2; i += NT) {
                     const int lo = 2 * i - (i & (stride - 1)), hi = lo + stride;
                     const uint64_t x = cand[lo], y = cand[hi];
                     if ((x < y) == ((lo & size) == 0)) {
@@ -85,13 +99,13 @@ __device__ __forceinline__ void rank_and_emit(uint64_t* cand, int n, int k, uint
                 }
                 __syncthreads();
             }
-        for (int i = threadIdx.x; i < k; i += NT) out[i] = i < n ? cand[i] : 0;
+        for (int i = tidx; i < k; i += NT) out[i] = i < n ? cand[i] : 0;
         return;
     }
     if (n <= 64) {
         // one wave, keys in registers, partner keys broadcast with v_readlane (no LDS round trips)
-        if (threadIdx.x < 64) {
-            const int lane = (int)threadIdx.x;
+        if (tidx < 64) {
+            const int lane = tidx;
             const uint64_t me = lane < n ? cand[lane] : 0ull;
             const uint32_t lo = (uint32_t)me, hi = (uint32_t)(me >> 32);
             int rank = 0;
@@ -105,13 +119,13 @@ __device__ __forceinline__ void rank_and_emit(uint64_t* cand, int n, int k, uint
         }
         return;
     }
-    for (int i = threadIdx.x; i < n; i += NT) {
+    for (int i = tidx; i < n; i += NT) {
         const uint64_t me = cand[i];
         int rank = 0;
         for (int j = 0; j < n; ++j) rank += cand[j] > me;
         if (rank < k) out[rank] = me;
     }
-    for (int i = n + (int)threadIdx.x; i < k; i += NT) out[i] = 0;
+    for (int i = n + tidx; i < k; i += NT) out[i] = 0;
 }
 
 struct SelectScratch {
@@ -149,12 +163,18 @@ struct TileLds {
 // Exact top-k of one accumulator tile held in LDS (shared by score_tiles and select_tiles).
 // Thread `tid` owns vec r*NT + tid of the accumulators in round r (conflict-free ds_read_b128); the accumulators are
 // re-read from LDS in every pass instead of being held in registers. Writes k keys best-first (0 = empty slot).
-template <int TILE_DOCS, int NT, int CAND, class Stamp>
+// `hook_a` runs right after the first barrier and `hook_b` right after the candidate barrier (score_tiles issues the
+// next query's loads there, so that they are in flight during the rest of the selection); neither runs when the tile
+// matched nothing (early return).
+struct NoHook {
+    __device__ __forceinline__ void operator()() const {}
+};
+template <int TILE_DOCS, int NT, int CAND, class Stamp, class HookA = NoHook, class HookB = NoHook>
 __device__ __forceinline__ void tile_select(const uint4* a4, uint64_t* cand, uint32_t* tmax, uint32_t* wmax,
                                             SelectScratch& ss, int rounds, uint64_t doc0, int k,
-                                            uint64_t* __restrict__ out, Stamp stamp) {
+                                            uint64_t* __restrict__ out, Stamp stamp, const uint32_t tid,
+                                            HookA hook_a = HookA(), HookB hook_b = HookB()) {
     constexpr int NW = NT / 64;
-    const uint32_t tid = threadIdx.x;
     const uint32_t lane = tid & 63;
     const uint32_t wave = rfl(tid >> 6);
     uint32_t mymax = 0;
@@ -172,6 +192,7 @@ __device__ __forceinline__ void tile_select(const uint4* a4, uint64_t* cand, uin
     if ((lane & (G - 1)) == 0) wmax[tid / G] = gm;
     if (k > 64) tmax[tid] = mymax;
     __syncthreads();
+    hook_a();
 
     uint32_t tau0 = 1, smax;
     {
@@ -234,6 +255,7 @@ __device__ __forceinline__ void tile_select(const uint4* a4, uint64_t* cand, uin
     __syncthreads();
     stamp(5);  // candidate collection
     uint32_t n_cand = ss.n_cand;
+    hook_b();
 
     if (n_cand > CAND) {
         // ---- fallback (mass ties, or k in the hundreds): exact selection by bisection.
@@ -301,7 +323,7 @@ __device__ __forceinline__ void tile_select(const uint4* a4, uint64_t* cand, uin
         __syncthreads();
         n_cand = min(ss.n_cand, (uint32_t)CAND);  // == min(k, #positive) <= CAND by construction
     }
-    rank_and_emit<NT, (CAND > 512)>(cand, (int)n_cand, k, out);
+    rank_and_emit<NT, (CAND > 512)>(cand, (int)n_cand, k, out, tid);
 }
 
 
