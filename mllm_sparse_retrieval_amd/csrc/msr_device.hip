@@ -316,7 +316,8 @@ static int batch_create_impl(msr_index* ix, const int64_t* q_ptr, const int32_t*
     // ---- host-side query normalisation (what pyserini does before handing the query to Lucene):
     // OOV (term < 0) and non-positive weights vanish, terms present in every doc are dropped when asked,
     // and the worst-case score must fit the u32 accumulators.
-    std::vector<uint32_t> qptr((size_t)nq + 1, 0), qterm, qw;
+    // per query {first term, end term, bit mask of its dense-head pairs, 0}: ONE scalar load in score_tiles
+    std::vector<uint32_t> qptr((size_t)nq * 4 + 4, 0), qterm, qw;
     const int64_t total_in = q_ptr[nq];
     if (total_in < 0 || (total_in && (!q_term || !q_w))) {
         set_error("msr_batch_create: bad CSR arrays");
@@ -366,8 +367,11 @@ static int batch_create_impl(msr_index* ix, const int64_t* q_ptr, const int32_t*
                 qw.push_back((uint32_t)w);
             }
         }
-        for (uint32_t s2 = 0; s2 < h->n_dense; ++s2)
+        uint32_t pmask = 0;
+        for (uint32_t s2 = 0; s2 < h->n_dense; ++s2) {
             qdense[(size_t)i * n_pairs + (s2 >> 1)] |= dsum[s2] << (16 * (s2 & 1));
+            if (dsum[s2]) pmask |= 1u << (s2 >> 1);
+        }
         if (bound > 0xFFFFFFFFull) {
             set_error("query %d: worst-case score %llu exceeds the exact u32 range", i, (unsigned long long)bound);
             return MSR_E_OVERFLOW;
@@ -376,7 +380,9 @@ static int batch_create_impl(msr_index* ix, const int64_t* q_ptr, const int32_t*
             set_error("query batch too large");
             return MSR_E_RANGE;
         }
-        qptr[i + 1] = (uint32_t)qterm.size();
+        qptr[(size_t)i * 4 + 1] = (uint32_t)qterm.size();
+        qptr[(size_t)i * 4 + 2] = pmask;
+        qptr[(size_t)i * 4 + 4] = (uint32_t)qterm.size();  // the next query's first term
     }
 
     msr_batch* b = new (std::nothrow) msr_batch;
@@ -404,7 +410,7 @@ static int batch_create_impl(msr_index* ix, const int64_t* q_ptr, const int32_t*
     // one input block (q_ptr | q_term | q_w | q_dense) and one output block (ord | u32 scores | f32 scores | n), both
     // from the handle's caching pool; small batches travel through pinned staging in ONE copy each way
     auto al = [](size_t n) { return (n + 63) / 64 * 64; };  // sub-buffers start on 256-byte boundaries (in u32 units)
-    const size_t o_ptr = 0, o_term = o_ptr + al((size_t)nq + 1), o_w = o_term + al(qterm.size()),
+    const size_t o_ptr = 0, o_term = o_ptr + al(qptr.size()), o_w = o_term + al(qterm.size()),
                  o_dense = o_w + al(qw.size()), in_words = o_dense + al(qdense.size());
     const size_t o_ord = 0, o_su = o_ord + al(nqk), o_sf = o_su + al(nqk), o_n = o_sf + al(nqk), out_words = o_n + al((size_t)nq);
     auto take = [&](size_t bytes) -> void* {
@@ -442,7 +448,7 @@ static int batch_create_impl(msr_index* ix, const int64_t* q_ptr, const int32_t*
         }
         if (d->h_stage && d->h_stage_bytes >= in_bytes && in_bytes <= (8u << 20)) {
             uint32_t* hs = (uint32_t*)d->h_stage;
-            memcpy(hs + o_ptr, qptr.data(), ((size_t)nq + 1) * 4);
+            memcpy(hs + o_ptr, qptr.data(), qptr.size() * 4);
             if (!qterm.empty()) {
                 memcpy(hs + o_term, qterm.data(), qterm.size() * 4);
                 memcpy(hs + o_w, qw.data(), qw.size() * 4);
@@ -452,7 +458,7 @@ static int batch_create_impl(msr_index* ix, const int64_t* q_ptr, const int32_t*
             ok = hipMemcpyAsync(d_in, hs, in_bytes, hipMemcpyHostToDevice, d->stream) == hipSuccess &&
                  hipStreamSynchronize(d->stream) == hipSuccess;
         } else {
-            ok = hipMemcpy(b->d_qptr, qptr.data(), ((size_t)nq + 1) * 4, hipMemcpyHostToDevice) == hipSuccess &&
+            ok = hipMemcpy(b->d_qptr, qptr.data(), qptr.size() * 4, hipMemcpyHostToDevice) == hipSuccess &&
                  (qterm.empty() || (hipMemcpy(b->d_qterm, qterm.data(), qterm.size() * 4, hipMemcpyHostToDevice) == hipSuccess &&
                                     hipMemcpy(b->d_qw, qw.data(), qw.size() * 4, hipMemcpyHostToDevice) == hipSuccess)) &&
                  (qdense.empty() || hipMemcpy(b->d_qdense, qdense.data(), qdense.size() * 4, hipMemcpyHostToDevice) == hipSuccess);
@@ -507,7 +513,7 @@ int batch_search_local(msr_batch* b, int k, bool final_arrays) {
     ScoreArgs sa;
     sa.seg_ptr = d->d_seg_ptr;
     sa.postings = d->d_postings;
-    sa.q_ptr = b->d_qptr;
+    sa.q_meta = reinterpret_cast<const uint4*>(b->d_qptr);
     sa.q_term = b->d_qterm;
     sa.q_w = b->d_qw;
     sa.dense = d->d_dense;
@@ -943,7 +949,7 @@ static void fill_score_args(ScoreArgs& sa, msr_batch* b, int k) {
     DeviceIndex* d = ix->dev;
     sa.seg_ptr = d->d_seg_ptr;
     sa.postings = d->d_postings;
-    sa.q_ptr = b->d_qptr;
+    sa.q_meta = reinterpret_cast<const uint4*>(b->d_qptr);
     sa.q_term = b->d_qterm;
     sa.q_w = b->d_qw;
     sa.dense = d->d_dense;

@@ -98,7 +98,7 @@ struct DeviceIndex {
 struct ScoreArgs {
     const uint32_t* seg_ptr;   // [ntiles][n_terms+1]
     const uint32_t* postings;  // shard base
-    const uint32_t* q_ptr;     // [nq+1]
+    const uint4* q_meta;       // [nq] {first term, end term, bit mask of the query's dense-head pairs, 0}
     const uint32_t* q_term;
     const uint32_t* q_w;
     const uint32_t* dense;     // [ntiles][n_pairs][TILE_DOCS] dense head (weights of term 2p+1 << 16 | term 2p)

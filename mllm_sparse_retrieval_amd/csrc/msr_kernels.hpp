@@ -68,7 +68,8 @@ __global__ __launch_bounds__(NT, MIN_WAVES) void score_tiles(const ScoreArgs a) 
     const int rounds = (int)((ndocs_tile + 4 * NT - 1) / (4 * NT));
     uint4* const a4 = reinterpret_cast<uint4*>(acc);
 
-    const uint32_t qb = a.q_ptr[q], qe = a.q_ptr[q + 1];
+    const uint4 meta = a.q_meta[q];  // one scalar load: term range + which dense-head pairs the query holds
+    const uint32_t qb = meta.x, qe = meta.y;
     const uint32_t* seg_row = a.seg_ptr + (uint64_t)tile_l * (a.n_terms + 1);
     // Postings and dense rows are read with buffer loads: (tile base + size in SGPRs) + (32-bit byte offset per
     // lane). A tile's segments span less than 4 GiB (checked when the index is attached); there is no 64-bit address
@@ -98,7 +99,8 @@ __global__ __launch_bounds__(NT, MIN_WAVES) void score_tiles(const ScoreArgs a) 
         typedef unsigned short us2 __attribute__((ext_vector_type(2)));
         constexpr int RG = 4;  // rounds per register group
         const uint32_t qv = lane < a.n_pairs ? a.q_dense[(uint64_t)q * a.n_pairs + lane] : 0u;
-        const uint32_t pmask = (DBG && (a.dbg & 16u)) ? 0u : (uint32_t)__ballot(qv != 0);  // n_pairs <= 16
+        // (the mask comes with the scalar load above, so the first rows are requested without waiting for qv)
+        const uint32_t pmask = (DBG && (a.dbg & 16u)) ? 0u : meta.z;
         const __amdgpu_buffer_rsrc_t rs_dense =
             make_rsrc(reinterpret_cast<const char*>(a.dense) + (uint64_t)tile_l * a.n_pairs * (TILE_DOCS * 4u),
                       a.n_pairs * (uint32_t)(TILE_DOCS * 4));
