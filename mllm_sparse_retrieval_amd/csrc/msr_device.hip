@@ -11,13 +11,15 @@
 namespace msr {
 
 // ------------------------------------------------------------------------------------------------ launch
-static int launch_score(hipStream_t st, uint32_t tile_docs, uint32_t ntiles, const ScoreArgs& a0, bool dump = false) {
-    if (ntiles == 0 || a0.qn == 0) return MSR_OK;
+// scores the shard-local tiles [t_begin, t_end) for queries [a0.q0, a0.q0 + a0.qn)
+static int launch_score(hipStream_t st, uint32_t tile_docs, uint32_t t_begin, uint32_t t_end, const ScoreArgs& a0,
+                        bool dump = false) {
+    if (t_end <= t_begin || a0.qn == 0) return MSR_OK;
     // grid = (queries, tiles): x runs fastest in dispatch order, so the workgroups in flight share a tile
-    for (uint32_t tl0 = 0; tl0 < ntiles; tl0 += kMaxGridY) {
+    for (uint32_t tl0 = t_begin; tl0 < t_end; tl0 += kMaxGridY) {
         ScoreArgs a = a0;
         a.tl0 = tl0;
-        const dim3 grid(a.qn, std::min<uint32_t>(kMaxGridY, ntiles - tl0));
+        const dim3 grid(a.qn, std::min<uint32_t>(kMaxGridY, t_end - tl0));
         switch (tile_docs) {
 #define MSR_LAUNCH(T, N, UU, W, WR)                                                                \
     if (dump)                                                                                      \
@@ -529,6 +531,8 @@ int batch_search_local(msr_batch* b, int k, bool final_arrays) {
     sa.qn = (uint32_t)b->nq;
     sa.k = (uint32_t)k;
     sa.dump = nullptr;
+    sa.theta = nullptr;
+    sa.tl0 = 0;
     sa.tpr = 1;
     sa.dump_add = 0;
     {
@@ -543,13 +547,35 @@ int batch_search_local(msr_batch* b, int k, bool final_arrays) {
             sa.stamps = b->d_stamps;
         }
     }
-    // one launch holds at most 2^31-1 workgroups (tiles x queries): larger batches go in query ranges
+    // Staged search: the first `t1` tiles are scored with the full per-tile selection; their merged k-th best key
+    // per query is a lower bound on the final k-th key, so the remaining tiles only have to report keys at or above
+    // it (theta_select: one pass, usually no survivor). Exact: the final merge sees every key that can be in the
+    // top-k. (A launch holds at most 65535 tiles in y; x = queries.)
     int rc = MSR_OK;
-    const uint32_t q_step = ix->shard_ntiles ? std::max<uint32_t>(0x7FFFFFFFu / ix->shard_ntiles, 1u) : (uint32_t)b->nq;
-    for (uint32_t q0 = 0; q0 < (uint32_t)b->nq; q0 += q_step) {
-        sa.q0 = q0;
-        sa.qn = std::min<uint32_t>(q_step, (uint32_t)b->nq - q0);
-        rc = launch_score(d->stream, h->tile_docs, ix->shard_ntiles, sa);
+    const uint32_t nt = ix->shard_ntiles;
+    static const int stage_env = getenv("MSR_STAGE1_TILES") ? atoi(getenv("MSR_STAGE1_TILES")) : -1;
+    uint32_t t1 = nt;
+    if (nt >= 2 && !sa.dbg && stage_env != 0)
+        t1 = stage_env > 0 ? std::min<uint32_t>(nt, (uint32_t)stage_env) : std::max<uint32_t>(1u, nt / kStage1Fraction);
+    sa.theta = nullptr;
+    rc = launch_score(d->stream, h->tile_docs, 0, t1, sa);
+    if (rc != MSR_OK) return rc;
+    if (t1 < nt) {
+        MergeArgs m1;
+        m1.lists = b->d_part;
+        m1.list_stride = (uint64_t)b->nq * k;
+        m1.n_lists = t1;
+        m1.nq = (uint32_t)b->nq;
+        m1.k = (uint32_t)k;
+        m1.out_keys = b->d_keys;
+        m1.out_ord = nullptr;
+        m1.out_score_u32 = nullptr;
+        m1.out_score = nullptr;
+        m1.out_n = nullptr;
+        rc = launch_merge(d->stream, m1);
+        if (rc != MSR_OK) return rc;
+        sa.theta = b->d_keys;
+        rc = launch_score(d->stream, h->tile_docs, t1, nt, sa);
         if (rc != MSR_OK) return rc;
     }
     HIP_TRY(hipEventRecord(b->ev1, d->stream));
@@ -965,6 +991,8 @@ static void fill_score_args(ScoreArgs& sa, msr_batch* b, int k) {
     sa.qn = (uint32_t)b->nq;
     sa.k = (uint32_t)k;
     sa.dump = nullptr;
+    sa.theta = nullptr;
+    sa.tl0 = 0;
     sa.tpr = 1;
     sa.dump_add = 0;
     sa.dbg = 0;
@@ -1015,7 +1043,7 @@ int msr_batch_search_termshard(msr_batch* b, int k) {
         sa.qn = qn;
         sa.dump = b->d_S;
         sa.tpr = p.tpr;
-        rc = launch_score(d->stream, h->tile_docs, h->n_tiles, sa, true);
+        rc = launch_score(d->stream, h->tile_docs, 0, h->n_tiles, sa, true);
         if (rc != MSR_OK) return rc;
         const uint32_t* reduced = b->d_S;
         if (p.G > 1) {
@@ -1128,7 +1156,7 @@ int msr_search_termshard_emulated(msr_index* ix, const int64_t* q_ptr, const int
             sa.dump = d_S;
             sa.tpr = p.tpr;
             sa.dump_add = 1;
-            rc = launch_score(d->stream, h->tile_docs, h->n_tiles, sa, true);
+            rc = launch_score(d->stream, h->tile_docs, 0, h->n_tiles, sa, true);
         }
         for (int r = 0; r < n_shards && rc == MSR_OK; ++r) {
             SelectArgs se;

@@ -28,6 +28,7 @@ namespace msr {
 constexpr int kQtBlock = 256;    // query terms staged in LDS per round
 constexpr int kCandCap = 1024;   // candidate keys per workgroup (>= MSR_KMAX)
 constexpr uint32_t kMaxGridY = 65535;  // HIP grid limit in y (tiles per launch)
+constexpr uint32_t kStage1Fraction = 16;  // staged search: 1/16 of the tiles (at least one) set the thresholds
 constexpr int kChunkVecs = 64;   // one chunk = one wave-wide uint4 load = 256 postings = 1 KiB
 static_assert(kCandCap >= MSR_KMAX, "candidate buffer must hold k keys");
 
@@ -105,6 +106,7 @@ struct ScoreArgs {
     const uint32_t* q_dense;   // [nq][n_pairs] packed query weights of the dense-head terms (0 = absent)
     uint32_t n_pairs;
     uint64_t* part;            // [ntiles][nq][k] keys
+    const uint64_t* theta;     // [nq][k] best keys of an earlier launch's tiles (staged search), or null
     uint64_t n_docs;           // whole index
     uint32_t vec_base;
     uint32_t n_terms;

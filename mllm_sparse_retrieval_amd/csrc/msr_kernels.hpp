@@ -69,6 +69,8 @@ __global__ __launch_bounds__(NT, MIN_WAVES) void score_tiles(const ScoreArgs a) 
     uint4* const a4 = reinterpret_cast<uint4*>(acc);
 
     const uint4 meta = a.q_meta[q];  // one scalar load: term range + which dense-head pairs the query holds
+    // staged search: the query's k-th best key over the tiles of an earlier launch (0: fewer than k hits so far)
+    const uint64_t theta = (MODE == 0 && a.theta) ? a.theta[(uint64_t)q * a.k + (a.k - 1)] : 0ull;
     const uint32_t qb = meta.x, qe = meta.y;
     const uint32_t* seg_row = a.seg_ptr + (uint64_t)tile_l * (a.n_terms + 1);
     // Postings and dense rows are read with buffer loads: (tile base + size in SGPRs) + (32-bit byte offset per
@@ -305,6 +307,10 @@ __global__ __launch_bounds__(NT, MIN_WAVES) void score_tiles(const ScoreArgs a) 
         return;
     }
 
+    if (theta && theta_select<TILE_DOCS, NT, CAND>(a4, cand, ss, rounds, doc0, k, out, theta, tid)) {
+        stamp(6);
+        return;
+    }
     tile_select<TILE_DOCS, NT, CAND>(a4, cand, tmax, wmax, ss, rounds, doc0, k, out, stamp, tid);
     stamp(6);  // ranking + output
 }

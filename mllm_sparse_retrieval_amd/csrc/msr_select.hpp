@@ -327,4 +327,48 @@ __device__ __forceinline__ void tile_select(const uint4* a4, uint64_t* cand, uin
 }
 
 
+// Top-k of a tile when a lower bound `th` on the query's GLOBAL k-th key is already known (the k-th best key over the
+// tiles scored by an earlier launch, msr_device.hip: staged search). A key below `th` cannot reach the final top-k,
+// so the tile's survivors are the accumulators with key >= th — usually none or a handful: one pass over the
+// accumulators, one barrier, and the (tiny) ranking; no group maxima, no threshold bisection. The list may hold fewer
+// than k keys (the merge treats 0 as an empty slot). Returns false, with the scratch reset, when more than CAND keys
+// survive (the caller then runs the full tile_select).
+template <int TILE_DOCS, int NT, int CAND>
+__device__ __forceinline__ bool theta_select(const uint4* a4, uint64_t* cand, SelectScratch& ss, int rounds,
+                                             uint64_t doc0, int k, uint64_t* __restrict__ out, const uint64_t th,
+                                             const uint32_t tid) {
+    const uint32_t ts = (uint32_t)(th >> 32);
+    uint32_t mymax = 0;
+    for (int r = 0; r < rounds; ++r) {
+        const uint4 x = a4[r * NT + tid];
+        mymax = max(max(mymax, max(x.x, x.y)), max(x.z, x.w));
+    }
+    if (mymax >= ts) {
+        for (int r = 0; r < rounds; ++r) {
+            const uint4 x = a4[r * NT + tid];
+            const uint32_t sc4[4] = {x.x, x.y, x.z, x.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (sc4[e] >= ts) {
+                    const uint32_t local = 4 * (r * NT + tid) + e;
+                    const uint64_t key = ((uint64_t)sc4[e] << 32) | (uint64_t)(0xFFFFFFFFu - (uint32_t)(doc0 + local));
+                    if (key >= th) {
+                        const uint32_t pos = atomicAdd(&ss.n_cand, 1u);
+                        if (pos < CAND) cand[pos] = key;
+                    }
+                }
+        }
+    }
+    __syncthreads();
+    const uint32_t n_cand = ss.n_cand;
+    if (n_cand > CAND) {
+        __syncthreads();  // everyone has read n_cand
+        if (tid == 0) ss.n_cand = 0;
+        __syncthreads();
+        return false;
+    }
+    rank_and_emit<NT, (CAND > 512)>(cand, (int)n_cand, k, out, tid);
+    return true;
+}
+
 }  // namespace msr
