@@ -45,6 +45,7 @@ __global__ __launch_bounds__(NT, MIN_WAVES) void score_tiles(const ScoreArgs a) 
 
     const uint32_t tid = threadIdx.x;
     const uint32_t lane = tid & 63;
+    const uint32_t lane16 = lane * 16u;         // byte offset of the lane's vec inside a chunk
     const uint32_t wave = rfl(tid >> 6);        // provably wave-uniform for the compiler
     // diagnostic build only: wave 0 stamps s_memtime at phase boundaries and adds the deltas to a side buffer
     long long t_prev = 0;
@@ -130,8 +131,7 @@ __global__ __launch_bounds__(NT, MIN_WAVES) void score_tiles(const ScoreArgs a) 
                     }
                 };
                 uint32_t m = pmask;
-                uint4 xa[RG] = {}, xb[RG] = {};  // (defined on every path: an undefined value at the top of a loop
-                                                 // body is folded into "the previous iteration's value" and stays live)
+                uint4 xa[RG], xb[RG];
                 uint32_t pa = (uint32_t)__builtin_ctz(m), pb = 0;
                 m &= m - 1;
                 load_rows(xa, pa);
@@ -220,9 +220,10 @@ __global__ __launch_bounds__(NT, MIN_WAVES) void score_tiles(const ScoreArgs a) 
                 const uint32_t mid = lo + step;
                 lo = pref[mid] <= my_c ? mid : lo;
             }
+            // (byte units: the loads below take them as scalar offset / clamp without further arithmetic)
             const uint32_t voff = (my_c - pref[lo]) * kChunkVecs;
-            const uint32_t m_base = my_i < c_end ? seg_start[lo] + voff : 0u;  // idle slots re-read the tile's first vec
-            const uint32_t m_n = my_i < c_end ? min((uint32_t)kChunkVecs, seg_len[lo] - voff) : 0u;
+            const uint32_t m_b16 = my_i < c_end ? (seg_start[lo] + voff) << 4 : 0u;  // idle slots: the tile's first vec
+            const uint32_t m_n16 = my_i < c_end ? min((uint32_t)kChunkVecs, seg_len[lo] - voff) << 4 : 0u;
             const uint32_t m_w = seg_w[lo];
             stamp(7);  // lane-parallel chunk resolution (binary search)
             if (DBG && (a.dbg & 256u)) break;  // ablation: stop after the first chunk resolution
@@ -235,14 +236,16 @@ __global__ __launch_bounds__(NT, MIN_WAVES) void score_tiles(const ScoreArgs a) 
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
                     const uint32_t idx = u0 + u;  // < 64: u0 + U <= nchunk rounded up to a multiple of U
-                    const uint32_t b = rdl(m_base, idx);
-                    const uint32_t n = rdl(m_n, idx);
+                    const uint32_t b16 = rdl(m_b16, idx);
+                    const uint32_t n16 = rdl(m_n16, idx);
                     if (DBG && (a.dbg & 2u)) {  // ablation: no global loads, synthetic postings
                         const uint32_t hsh = ((cb + idx) * 64u + lane) * 2654435761u;
                         v[u] = make_uint4((1u << 16) | (hsh >> 17), (1u << 16) | ((hsh * 31u) >> 17),
                                           (1u << 16) | ((hsh * 131u) >> 17), (1u << 16) | ((hsh * 1031u) >> 17));
                     } else {
-                        v[u] = buf_load16(rs_post, (b + (lane < n ? lane : 0u)) << 4, 0u);
+                        // lanes past the chunk's end re-read its last vec (same cache line); an idle slot (n16 = 0:
+                        // the clamp wraps to 2^32 - 16) reads the tile's first vecs; all inside the tile or zero
+                        v[u] = buf_load16(rs_post, min(lane16, n16 - 16u), b16);
                     }
                 }
             };
@@ -250,11 +253,11 @@ __global__ __launch_bounds__(NT, MIN_WAVES) void score_tiles(const ScoreArgs a) 
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
                     const uint32_t idx = u0 + u;
-                    const uint32_t n = rdl(m_n, idx);  // 0 in the slots past nchunk
+                    const uint32_t n16 = rdl(m_n16, idx);  // 0 in the slots past nchunk
                     const uint32_t w = rdl(m_w, idx);
                     // lanes past the chunk's last vec must not touch LDS (64 lanes adding to one accumulator would
                     // serialise); padding INSIDE a vec has weight 0 and a lane-distinct ordinal
-                    if (lane < n) {
+                    if (lane16 < n16) {
                         const uint32_t p[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
                         if (DBG && (a.dbg & 1u)) {  // ablation: no LDS atomics (keep the loads alive)
                             if ((p[0] ^ p[1] ^ p[2] ^ p[3]) == 0xDEADBEEFu) atomicAdd(&acc[0], 1u);
@@ -267,7 +270,7 @@ __global__ __launch_bounds__(NT, MIN_WAVES) void score_tiles(const ScoreArgs a) 
                     }
                 }
             };
-            uint4 va[U] = {}, vb[U] = {};  // (as xa / xb)
+            uint4 va[U], vb[U];
             load_bank(va, 0);
             for (uint32_t u0 = 0; u0 < nchunk; u0 += 2 * U) {
                 const bool more = u0 + U < nchunk;  // wave-uniform
