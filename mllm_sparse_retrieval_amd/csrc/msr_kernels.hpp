@@ -215,8 +215,8 @@ __global__ __launch_bounds__(NT, MIN_WAVES) void score_tiles(const ScoreArgs a) 
             // search for a chunk that does not exist — their reads stay inside pref[] and their m_n is forced to 0.
             const uint32_t my_c = wave + my_i * NW;
             uint32_t lo = 0;
-            for (uint32_t step = kQtBlock >> 1; step > 0; step >>= 1) {
-                if (step >= cnt) continue;  // wave-uniform: lo + step >= cnt can never be taken
+            // first step = largest power of two below cnt (lo + step >= cnt can never be taken); none when cnt == 1
+            for (uint32_t step = cnt > 1 ? 1u << (31 - __clz((int)(cnt - 1))) : 0u; step > 0; step >>= 1) {
                 const uint32_t mid = lo + step;
                 lo = pref[mid] <= my_c ? mid : lo;
             }

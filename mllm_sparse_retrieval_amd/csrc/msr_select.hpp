@@ -109,10 +109,13 @@ __device__ __forceinline__ void rank_and_emit(uint64_t* cand, int n, int k, uint
             const uint64_t me = lane < n ? cand[lane] : 0ull;
             const uint32_t lo = (uint32_t)me, hi = (uint32_t)(me >> 32);
             int rank = 0;
-            for (int j = 0; j < n; ++j) {
-                const uint64_t o = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)hi, j) << 32) |
-                                   (uint32_t)__builtin_amdgcn_readlane((int)lo, j);
-                rank += o > me;
+            for (int j = 0; j < n; j += 4) {  // lanes n..63 hold key 0, which outranks nobody: no tail guard
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const uint64_t o = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)hi, j + u) << 32) |
+                                       (uint32_t)__builtin_amdgcn_readlane((int)lo, j + u);
+                    rank += o > me;
+                }
             }
             if (lane < n && rank < k) out[rank] = me;
             for (int i = n + lane; i < k; i += 64) out[i] = 0;
