@@ -144,10 +144,15 @@ def roofline(batch, k, score_ms_avg, workload_name):
             traffic = json.load(open(tf)).get(workload_name)
         except Exception:
             traffic = None
+    # One step = the staged search's two score_tiles launches (first 1/16 of the tiles, then the rest with the
+    # thresholds those gave): bytes, traffic and kernel_ms are all per step, i.e. summed over both.
     return {"bound": "hbm", "kernel": "score_tiles", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
             "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
             "algorithmic_bytes_per_launch": by, "postings_per_launch": postings,
-            "kernel_ms": round(score_ms_avg, 4)}
+            "kernel_ms": round(score_ms_avg, 4), "launches_per_step": 2 if batch.index.n_tiles >= 2 else 1,
+            "note": "frac > 1: the postings of a tile are re-read by every query from the XCDs' L2, not from HBM "
+                    "(traffic = measured HBM-side bytes per step); the kernel's own limiters are VALU issue "
+                    "(64-74 % busy) and L2->CU bandwidth (DESIGN.md §7)"}
 
 
 def cpu_baseline(wl, got, target_seconds, threads):

@@ -210,7 +210,7 @@ __device__ __forceinline__ void tile_select(const uint4* a4, uint64_t* cand, uin
             // CU's 32 waves (eight waves repeating the search cost more than the extra barrier). The bisection stops
             // after kTauBits significant bits: tau0 is then a slightly lower bound (a few more candidates), still
             // with at least k accumulators at or above it.
-            constexpr int kTauBits = 12;
+            constexpr int kTauBits = 8;
             if (wave == 0) {
                 const int top = 31 - __clz(smax);
                 const int low = max(top - (kTauBits - 1), 0);

@@ -4,14 +4,21 @@ usage: summarize_prof.py gpurun_out/prof_<tag>   (prefix; reads <prefix>_stats, 
 import collections
 import csv
 import glob
+import os
 import sys
 
+
+def newest(pattern):  # gpurun_out/ keeps the csv files of earlier calls: take the most recent one per pass
+    fs = sorted(glob.glob(pattern), key=os.path.getmtime)
+    return fs[-1:]
+
+
 prefix = sys.argv[1]
-for f in glob.glob(prefix + "_stats/*/*_kernel_stats.csv"):
+for f in newest(prefix + "_stats/*/*_kernel_stats.csv"):
     print("== kernel stats (rocprofv3 --kernel-trace --stats)")
     print(open(f).read().strip())
 for suffix in ("fetch", "l2", "sq", "sq2"):
-    for f in glob.glob(f"{prefix}_{suffix}/*/*_counter_collection.csv"):
+    for f in newest(f"{prefix}_{suffix}/*/*_counter_collection.csv"):
         agg = collections.defaultdict(list)
         for r in csv.DictReader(open(f)):
             agg[(r["Kernel_Name"].split("(")[0][-60:], r["Counter_Name"])].append(float(r["Counter_Value"]))
