@@ -232,12 +232,14 @@ __global__ __launch_bounds__(NT, MIN_WAVES) void score_tiles(const ScoreArgs a) 
             // the current bank's LDS atomics issue. Loads are unconditional (lanes past a chunk's end, and chunk
             // slots past nchunk, re-read the chunk's / the shard's first vec) so that the compiler can count them
             // with s_waitcnt vmcnt(N) instead of draining to vmcnt(0); only the atomics are predicated.
-            auto load_bank = [&](uint4 (&v)[U], uint32_t u0) {
+            // (a chunk's byte length stays in an SGPR from its load to its atomics: one v_readlane less per chunk)
+            auto load_bank = [&](uint4 (&v)[U], uint32_t (&sn16)[U], uint32_t u0) {
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
                     const uint32_t idx = u0 + u;  // < 64: u0 + U <= nchunk rounded up to a multiple of U
                     const uint32_t b16 = rdl(m_b16, idx);
                     const uint32_t n16 = rdl(m_n16, idx);
+                    sn16[u] = n16;
                     if (DBG && (a.dbg & 2u)) {  // ablation: no global loads, synthetic postings
                         const uint32_t hsh = ((cb + idx) * 64u + lane) * 2654435761u;
                         v[u] = make_uint4((1u << 16) | (hsh >> 17), (1u << 16) | ((hsh * 31u) >> 17),
@@ -249,11 +251,11 @@ __global__ __launch_bounds__(NT, MIN_WAVES) void score_tiles(const ScoreArgs a) 
                     }
                 }
             };
-            auto add_bank = [&](const uint4 (&v)[U], uint32_t u0) {
+            auto add_bank = [&](const uint4 (&v)[U], const uint32_t (&sn16)[U], uint32_t u0) {
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
                     const uint32_t idx = u0 + u;
-                    const uint32_t n16 = rdl(m_n16, idx);  // 0 in the slots past nchunk
+                    const uint32_t n16 = sn16[u];  // 0 in the slots past nchunk
                     const uint32_t w = rdl(m_w, idx);
                     // lanes past the chunk's last vec must not touch LDS (64 lanes adding to one accumulator would
                     // serialise); padding INSIDE a vec has weight 0 and a lane-distinct ordinal
@@ -271,14 +273,15 @@ __global__ __launch_bounds__(NT, MIN_WAVES) void score_tiles(const ScoreArgs a) 
                 }
             };
             uint4 va[U], vb[U];
-            load_bank(va, 0);
+            uint32_t na[U], nb[U];
+            load_bank(va, na, 0);
             for (uint32_t u0 = 0; u0 < nchunk; u0 += 2 * U) {
                 const bool more = u0 + U < nchunk;  // wave-uniform
-                if (more) load_bank(vb, u0 + U);
-                add_bank(va, u0);
+                if (more) load_bank(vb, nb, u0 + U);
+                add_bank(va, na, u0);
                 if (more) {
-                    if (u0 + 2 * U < nchunk) load_bank(va, u0 + 2 * U);
-                    add_bank(vb, u0 + U);
+                    if (u0 + 2 * U < nchunk) load_bank(va, na, u0 + 2 * U);
+                    add_bank(vb, nb, u0 + U);
                 }
             }
         }
