@@ -150,9 +150,10 @@ def roofline(batch, k, score_ms_avg, workload_name):
             "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
             "algorithmic_bytes_per_launch": by, "postings_per_launch": postings,
             "kernel_ms": round(score_ms_avg, 4), "launches_per_step": 2 if batch.index.n_tiles >= 2 else 1,
-            "note": "frac > 1: the postings of a tile are re-read by every query from the XCDs' L2, not from HBM "
-                    "(traffic = measured HBM-side bytes per step); the kernel's own limiters are VALU issue "
-                    "(64-74 % busy) and L2->CU bandwidth (DESIGN.md §7)"}
+            "note": "achieved = SURVEY §8d algorithmic bytes / kernel time; it can exceed the HBM peak because a tile's "
+                    "postings are re-read by every query from the XCDs' L2, not from HBM (traffic = measured HBM-side "
+                    "bytes per step); the kernel's own limiters are VALU issue (64-74 % busy) and L2->CU bandwidth "
+                    "(DESIGN.md §7)"}
 
 
 def cpu_baseline(wl, got, target_seconds, threads):
