@@ -281,6 +281,45 @@ def test_full_size_properties_c4(m, tmp_path):
     helpers.assert_same_results((o[:s], f[:s], u[:s], n[:s]), want, 10)
 
 
+def test_staged_search_thresholds(m, tmp_path):
+    """The staged search (first tiles -> per-query threshold -> remaining tiles report only keys at or above it):
+    hits that exist only in the last tile (no threshold from the first stage), a first stage that is beaten by every
+    later tile, exact score ties straddling the stage boundary (the lower ordinal of the first tile must win), and
+    thresholds that admit more survivors than the candidate buffer (fallback to the full per-tile selection)."""
+    tile, n_tiles = 4096, 20
+    n, V = tile * n_tiles, 12
+    rows_t, rows_w, ptr = [], [], [0]
+    rng = np.random.default_rng(5)
+    for d in range(n):
+        t_id = d // tile
+        terms, ws = [], []
+        if t_id == n_tiles - 1:            # term 0: only in the last tile
+            terms.append(0); ws.append(1 + d % 7)
+        terms.append(1); ws.append(1 + t_id)           # term 1: weight grows with the tile -> later tiles always win
+        terms.append(2); ws.append(5)                   # term 2: the same weight everywhere -> all scores tie
+        if d % 3 == 0:
+            terms.append(3); ws.append(int(rng.integers(1, 400)))  # term 3: random
+        terms.append(4 + d % 4); ws.append(2)           # terms 4-7: a quarter of the docs each, equal weights
+        rows_t += terms; rows_w += ws; ptr.append(len(rows_t))
+    docs = (np.array(ptr, dtype=np.uint64), np.array(rows_t, dtype=np.uint32), np.array(rows_w, dtype=np.uint32))
+    m.set_build_option("dense_max_terms", 0)
+    try:
+        path = m.build_index_from_csr(str(tmp_path / "s.idx"), *docs, V, tile_docs=tile)
+    finally:
+        m.set_build_option("dense_max_terms", 16)
+    queries = [[(0, 3)], [(1, 2)], [(2, 9)], [(3, 1), (2, 1)], [(4, 1)], [(1, 1), (3, 2), (5, 7)], [(0, 1), (2, 1)]]
+    qp = np.cumsum([0] + [len(q) for q in queries]).astype(np.int64)
+    qt = np.array([t for q in queries for t, _ in q], dtype=np.int32)
+    qw = np.array([w for q in queries for _, w in q], dtype=np.int32)
+    oix, _ = helpers.taat_oracle(docs, V)
+    with m.SparseIndex(path, device=0) as ix:
+        assert ix.n_tiles == n_tiles
+        for k in (1, 10, 64, 100, 600, 1024):
+            for drop in (False, True):
+                helpers.assert_same_results(ix.search_csr(qp, qt, qw, k, drop_df_eq_n=drop),
+                                            oix.search(qp, qt, qw, k, drop_df_eq_n=drop), k)
+
+
 def test_merge_of_many_tile_lists(m, tmp_path):
     # 37 tiles x k=100 = 3 700 partial keys per query: more than the merge kernel's LDS buffer, so the list-head
     # threshold path (and, with k = 1000 > #lists, the full bisection) is exercised
