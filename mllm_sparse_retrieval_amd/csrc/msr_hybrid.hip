@@ -34,6 +34,13 @@ __global__ __launch_bounds__(256) void dense_scores(const _Float16* __restrict__
     const uint32_t r = lane & 31, h = lane >> 5;
     const uint32_t wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
     const uint32_t q_blk = blockIdx.x * 128, d_blk = blockIdx.y * 128;
+    if (d_blk >= N) {  // a block of padding docs that select_tiles still reads (its rounds are 4*NT docs wide): keys 0
+        for (uint32_t i = tid; i < 128 * 32; i += 256) {
+            const uint32_t q = q_blk + i / 32;
+            if (q < M) reinterpret_cast<uint4*>(out + (uint64_t)q * ld + d_blk)[i % 32] = make_uint4(0, 0, 0, 0);
+        }
+        return;
+    }
     float16v acc[2][2];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -208,7 +215,11 @@ static int dense_search_impl(msr_dense* dx, const uint16_t* q_fp16, int nq, int 
             rc = MSR_E_HIP;
             break;
         }
-        hipLaunchKernelGGL(dense_scores, dim3(qn_pad / 128, (uint32_t)(dx->n_pad / 128)), dim3(256), 0, dx->stream, d_Q,
+        // doc blocks: up to the end of the last select round that holds a real doc (a round = 4 docs x threads of
+        // the select instance: 1024 docs at 4096-doc tiles, 2048 at 8192); padding beyond that is never read
+        const uint64_t round_docs = dx->tile_docs == 4096 ? 1024 : 2048;
+        const uint64_t n_cover = std::min<uint64_t>(dx->n_pad, (dx->n + round_docs - 1) / round_docs * round_docs);
+        hipLaunchKernelGGL(dense_scores, dim3(qn_pad / 128, (uint32_t)(n_cover / 128)), dim3(256), 0, dx->stream, d_Q,
                            dx->d_P, d_S, qn, (uint32_t)dx->n, dx->h, dx->n_pad);
         (void)hipEventRecord(e1, dx->stream);
         SelectArgs se;
