@@ -382,7 +382,18 @@ __global__ __launch_bounds__(NT) void merge_lists(const MergeArgs a) {
     __syncthreads();
 
     uint32_t n_cand;
-    if (n_items <= kCandCap) {
+    if (a.n_lists == 1) {
+        // a single list is already the answer, best first (single-tile indexes, e.g. the hybrid path's 5 000 docs at
+        // depth 1000): copy instead of ranking it again
+        for (int i = tid; i < k; i += NT) res[i] = key_at((uint32_t)i);
+        __syncthreads();
+        uint32_t c = 0;
+        for (int i = tid; i < k; i += NT) c += res[i] != 0;
+        c = wave_sum_u32(c);
+        if (lane == 0 && c) atomicAdd(&ss.n_cand, c);
+        __syncthreads();
+        n_cand = ss.n_cand;
+    } else if (n_items <= kCandCap) {
         for (uint32_t i = tid; i < n_items; i += NT) {
             const uint64_t key = key_at(i);
             if (key) cand[atomicAdd(&ss.n_cand, 1u)] = key;
@@ -443,7 +454,7 @@ __global__ __launch_bounds__(NT) void merge_lists(const MergeArgs a) {
         if (got > kCandCap) got = collect(bisect_kth(n_items, key_at));  // exactly min(k, #keys) <= kCandCap survive
         n_cand = min(got, (uint32_t)kCandCap);
     }
-    rank_and_emit<NT>(cand, (int)n_cand, k, res, tid);
+    if (a.n_lists != 1) rank_and_emit<NT>(cand, (int)n_cand, k, res, tid);
     __syncthreads();
     const int n_hit = min((int)n_cand, k);
     for (int i = tid; i < k; i += NT) {

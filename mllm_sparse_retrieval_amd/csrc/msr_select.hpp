@@ -261,68 +261,130 @@ __device__ __forceinline__ void tile_select(const uint4* a4, uint64_t* cand, uin
     hook_b();
 
     if (n_cand > CAND) {
-        // ---- fallback (mass ties, or k in the hundreds): exact selection by bisection.
-        //   1. tau = k-th largest SCORE of the tile: one bit per step, counted with ballots (scalar popcounts);
+        // ---- fallback (mass ties, or k in the hundreds): exact selection by radix passes over the score.
+        //   1. tau = k-th largest SCORE of the tile, one BYTE per pass, most significant first: a 256-bin LDS histogram
+        //      of the accumulators that match the bytes fixed so far, then every wave finds the bin that holds the
+        //      need-th largest (suffix sums over the bins: DPP scan + ballot) — 1-4 passes instead of 32 bisection steps;
         //   2. every accumulator above tau is in; of the c_eq accumulators equal to tau the `need` lowest ordinals are
-        //      in — found by a second bisection over the local ordinal only when there are more ties than needed.
+        //      in: a tie's rank among the ties is a prefix count in (round, thread, element) order = ascending ordinal
+        //      (wave scans + per-(round, wave) totals), no search.
         // Exactly min(k, #positive) <= CAND keys survive.
+        constexpr int R = TILE_DOCS / (4 * NT);  // rounds of a full tile
+        static_assert(NT >= 256 && R * NW <= NT, "the tie totals live in the NT-word tmax region");
+        // histogram: 256 bins x SUB lane-interleaved copies in the (still unused) candidate buffer — scores cluster, and
+        // 64 lanes adding to ONE LDS word serialise; with SUB copies on different banks a wave's adds to a hot bin
+        // spread over SUB words
+        constexpr int SUB = CAND / 128;  // 8 (k > 512 instances) or 4: 256 * SUB words = the CAND 8-byte keys
+        static_assert(SUB == 4 || SUB == 8, "candidate buffer of 512 or 1024 keys");
+        uint32_t* const hist = reinterpret_cast<uint32_t*>(cand);
+        uint32_t* const ties = tmax;  // per-(round, wave) tie totals (tmax is dead since tau0 was published)
         __syncthreads();  // everyone has read n_cand
         if (tid == 0) ss.n_cand = 0;
-        auto count_if = [&](auto pred) -> uint32_t {  // wave-level count over this wave's accumulators (uniform)
-            uint32_t c = 0;
+        uint32_t prefix = 0, hi_mask = 0, need = (uint32_t)k;
+        // first window = the 8 most significant bits of the tile's maximum (spreads the scores over up to 128 bins),
+        // then whole bytes below it; the last window may overlap bits that are already fixed (harmless)
+        for (int shift = max(31 - __clz(smax) - 7, 0);; shift = max(shift - 8, 0)) {
+            for (int i = tid; i < 256 * SUB / 4; i += NT) reinterpret_cast<uint4*>(hist)[i] = make_uint4(0, 0, 0, 0);
+            __syncthreads();
             for (int r = 0; r < rounds; ++r) {
                 const uint4 x = a4[r * NT + tid];
-                const uint32_t base = 4 * (r * NT + tid);
-                c += (uint32_t)__popcll(__ballot(pred(x.x, base))) + (uint32_t)__popcll(__ballot(pred(x.y, base + 1))) +
-                     (uint32_t)__popcll(__ballot(pred(x.z, base + 2))) + (uint32_t)__popcll(__ballot(pred(x.w, base + 3)));
+                const uint32_t sc4[4] = {x.x, x.y, x.z, x.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if ((sc4[e] & hi_mask) == prefix)
+                        atomicAdd(&hist[((sc4[e] >> shift) & 255u) * SUB + (lane & (SUB - 1))], 1u);
             }
-            return c;
-        };
-        int step = 0;
-        auto block_count = [&](uint32_t c) -> uint32_t {  // sum of the waves' counts, the same value on every thread
-            if (lane == 0 && c) atomicAdd(&ss.cnt[step], c);
             __syncthreads();
-            return ss.cnt[step++];
-        };
-        uint32_t tau = 0;
-        for (int bit = 31 - __clz(smax); bit >= 0; --bit) {
-            const uint32_t t2 = tau | (1u << bit);
-            if (block_count(count_if([&](uint32_t sc, uint32_t) { return sc >= t2; })) >= (uint32_t)k) tau = t2;
-        }
-        uint32_t o_star = 0xFFFFFFFFu;  // ties at tau with local ordinal <= o_star are selected
-        if (tau == 0) {
-            tau = 1;  // fewer than k positive accumulators: all of them
-        } else {
-            const uint32_t c_gt = block_count(count_if([&](uint32_t sc, uint32_t) { return sc > tau; }));
-            const uint32_t c_eq = block_count(count_if([&](uint32_t sc, uint32_t) { return sc == tau; }));
-            const uint32_t need = (uint32_t)k - c_gt;  // >= 1 by the definition of tau
-            if (c_eq > need) {
-                uint32_t lo = 0, hi = TILE_DOCS - 1;  // smallest o with #(ties, local <= o) >= need
-                while (lo < hi) {
-                    const uint32_t mid = (lo + hi) >> 1;
-                    const uint32_t c = block_count(count_if([&](uint32_t sc, uint32_t loc) { return sc == tau && loc <= mid; }));
-                    if (c >= need)
-                        hi = mid;
-                    else
-                        lo = mid + 1;
+            uint4 hb = make_uint4(0, 0, 0, 0);  // bins 4*lane .. 4*lane+3, summed over their SUB copies
+#pragma unroll
+            for (int c = 0; c < SUB; ++c) {
+                const uint4 t = reinterpret_cast<const uint4*>(hist)[lane * SUB + c];  // words 4*SUB*lane + 4c ..
+                // word index = bin * SUB + copy: the 4*SUB words of this lane hold bin 4*lane + (4c + j) / SUB
+                const uint32_t w4[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int b = (4 * c + j) / SUB;
+                    if (b == 0) hb.x += w4[j];
+                    if (b == 1) hb.y += w4[j];
+                    if (b == 2) hb.z += w4[j];
+                    if (b == 3) hb.w += w4[j];
                 }
-                o_star = lo;
+            }
+            const uint32_t s = hb.x + hb.y + hb.z + hb.w;
+            const uint32_t inc = wave_inclusive_scan_u32(s);
+            const uint32_t suf = rdl(inc, 63) - (inc - s);  // elements in bins >= 4*lane: non-increasing in lane
+            // (the matching elements number at least `need`: more than CAND >= k accumulators are positive here)
+            const uint32_t L = 63u - (uint32_t)__clzll((long long)__ballot(suf >= need));
+            uint32_t above = rdl(suf, L) - rdl(s, L);  // elements in the bins above lane L's four
+            const uint32_t b3 = rdl(hb.w, L), b2 = rdl(hb.z, L), b1 = rdl(hb.y, L);
+            uint32_t bin = 4 * L + 3;
+            if (above + b3 < need) {
+                above += b3;
+                bin = 4 * L + 2;
+                if (above + b2 < need) {
+                    above += b2;
+                    bin = 4 * L + 1;
+                    if (above + b1 < need) {
+                        above += b1;
+                        bin = 4 * L;
+                    }
+                }
+            }
+            need -= above;  // rank of the wanted element inside the chosen bin
+            prefix |= bin << shift;
+            hi_mask |= 255u << shift;
+            __syncthreads();  // the histogram is rewritten next (or becomes the candidate buffer again)
+            if (shift == 0) break;
+        }
+        const uint32_t tau = prefix;   // k-th largest score; 0: fewer than k positive accumulators (take them all)
+        if (tau == 0) need = 0;        // ... and none of the zeros
+        // rank of every tie among the ties, in ascending ordinal order
+        uint32_t first[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            first[r] = 0;
+            if (r < rounds) {
+                const uint4 x = a4[r * NT + tid];
+                const uint32_t c = (uint32_t)(x.x == tau) + (uint32_t)(x.y == tau) + (uint32_t)(x.z == tau) + (uint32_t)(x.w == tau);
+                const uint32_t inc = wave_inclusive_scan_u32(c);
+                if (lane == 63) ties[r * NW + wave] = inc;
+                first[r] = inc - c;  // ties of lower lanes of this wave in this round
             }
         }
         __syncthreads();
-        for (int r = 0; r < rounds; ++r) {
-            const uint4 x = a4[r * NT + tid];
-            const uint32_t sc4[4] = {x.x, x.y, x.z, x.w};
+        {
+            uint32_t run = 0;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const uint32_t local = 4 * (r * NT + tid) + e;
-                if (sc4[e] > tau || (sc4[e] == tau && local <= o_star)) {
-                    const uint32_t pos = atomicAdd(&ss.n_cand, 1u);
-                    if (pos < CAND)
-                        cand[pos] = ((uint64_t)sc4[e] << 32) | (uint64_t)(0xFFFFFFFFu - (uint32_t)(doc0 + local));
+            for (int r = 0; r < R; ++r)
+                if (r < rounds) {
+                    uint32_t row = 0, before = 0;
+                    for (int w = 0; w < NW; ++w) {
+                        const uint32_t v = ties[r * NW + w];
+                        before += (uint32_t)w < wave ? v : 0u;
+                        row += v;
+                    }
+                    first[r] += run + before;
+                    run += row;
+                }
+        }
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+            if (r < rounds) {
+                const uint4 x = a4[r * NT + tid];
+                const uint32_t sc4[4] = {x.x, x.y, x.z, x.w};
+                uint32_t tr = first[r];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    bool take = sc4[e] > tau;
+                    if (sc4[e] == tau) take = tr++ < need;
+                    if (take) {
+                        const uint32_t local = 4 * (r * NT + tid) + e;
+                        const uint32_t pos = atomicAdd(&ss.n_cand, 1u);
+                        if (pos < CAND)
+                            cand[pos] = ((uint64_t)sc4[e] << 32) | (uint64_t)(0xFFFFFFFFu - (uint32_t)(doc0 + local));
+                    }
                 }
             }
-        }
         __syncthreads();
         n_cand = min(ss.n_cand, (uint32_t)CAND);  // == min(k, #positive) <= CAND by construction
     }
