@@ -533,6 +533,7 @@ int batch_search_local(msr_batch* b, int k, bool final_arrays) {
     sa.dump = nullptr;
     sa.theta = nullptr;
     sa.tl0 = 0;
+    sa.unsorted = 0;
     sa.tpr = 1;
     sa.dump_add = 0;
     {
@@ -558,6 +559,7 @@ int batch_search_local(msr_batch* b, int k, bool final_arrays) {
     if (nt >= 2 && !sa.dbg && stage_env != 0)
         t1 = stage_env > 0 ? std::min<uint32_t>(nt, (uint32_t)stage_env) : std::max<uint32_t>(1u, nt / kStage1Fraction);
     sa.theta = nullptr;
+    sa.unsorted = (b->unsorted_ok && nt == 1) ? 1u : 0u;  // one tile: its list IS the query's list
     rc = launch_score(d->stream, h->tile_docs, 0, t1, sa);
     if (rc != MSR_OK) return rc;
     if (t1 < nt) {
@@ -993,6 +995,7 @@ static void fill_score_args(ScoreArgs& sa, msr_batch* b, int k) {
     sa.dump = nullptr;
     sa.theta = nullptr;
     sa.tl0 = 0;
+    sa.unsorted = 0;
     sa.tpr = 1;
     sa.dump_add = 0;
     sa.dbg = 0;
@@ -1055,6 +1058,7 @@ int msr_batch_search_termshard(msr_batch* b, int k) {
             reduced = b->d_R;
         }
         SelectArgs se;
+        se.unsorted = 0;
         se.src = reduced;
         se.part = b->d_tpart;
         se.n_docs = h->n_docs;
@@ -1160,6 +1164,8 @@ int msr_search_termshard_emulated(msr_index* ix, const int64_t* q_ptr, const int
         }
         for (int r = 0; r < n_shards && rc == MSR_OK; ++r) {
             SelectArgs se;
+            se.unsorted = 0;
+        se.unsorted = 0;
             se.src = d_S + (size_t)r * qn * p.range_elems;
             se.part = rank_part[r];
             se.n_docs = h->n_docs;

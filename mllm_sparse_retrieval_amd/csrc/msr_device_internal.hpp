@@ -107,6 +107,7 @@ struct ScoreArgs {
     uint32_t n_pairs;
     uint64_t* part;            // [ntiles][nq][k] keys
     const uint64_t* theta;     // [nq][k] best keys of an earlier launch's tiles (staged search), or null
+    uint32_t unsorted;         // 1: the tile's k keys may be emitted in any order (single-tile hybrid lists)
     uint64_t n_docs;           // whole index
     uint32_t vec_base;
     uint32_t n_terms;
@@ -134,6 +135,7 @@ struct SelectArgs {
     uint32_t tpr;
     uint32_t rank;
     uint32_t nq, q0, qn, k;
+    uint32_t unsorted;  // as ScoreArgs::unsorted
 };
 
 struct MergeArgs {
@@ -157,6 +159,7 @@ int launch_merge(hipStream_t st, const MergeArgs& a);
 
 struct msr_batch {
     msr_index* ix = nullptr;
+    bool unsorted_ok = false;  // hybrid path: the consumer of d_keys treats each query's list as a set
     int nq = 0;
     int kmax = 0;
     int last_k = 0;

@@ -170,7 +170,7 @@ void msr_dense_close(msr_dense* dx) {
 
 // to_device = true: out_* are DEVICE buffers ([nq][k] / [nq]) filled on dx->stream (hybrid path); else host buffers.
 static int dense_search_impl(msr_dense* dx, const uint16_t* q_fp16, int nq, int k, uint32_t* out_idx, uint32_t* out_key,
-                             int32_t* out_n, float* gemm_ms, float* select_ms, bool to_device) {
+                             int32_t* out_n, float* gemm_ms, float* select_ms, bool to_device, bool unsorted = false) {
     if (!dx || nq < 0 || (nq && !q_fp16) || !out_idx || !out_key || !out_n) {
         set_error("msr_dense_search: bad argument");
         return MSR_E_INVAL;
@@ -223,6 +223,7 @@ static int dense_search_impl(msr_dense* dx, const uint16_t* q_fp16, int nq, int 
                            dx->d_P, d_S, qn, (uint32_t)dx->n, dx->h, dx->n_pad);
         (void)hipEventRecord(e1, dx->stream);
         SelectArgs se;
+        se.unsorted = 0;
         se.src = d_S;
         se.part = d_part;
         se.n_docs = dx->n;
@@ -233,6 +234,7 @@ static int dense_search_impl(msr_dense* dx, const uint16_t* q_fp16, int nq, int 
         se.q0 = 0;
         se.qn = qn;
         se.k = (uint32_t)k;
+        se.unsorted = (unsorted && dx->n_tiles == 1) ? 1u : 0u;  // the fusion takes the list as a set
         rc = launch_select(dx->stream, dx->tile_docs, se);
         if (rc != MSR_OK) break;
         MergeArgs ma;
@@ -335,23 +337,46 @@ __global__ __launch_bounds__(NT) void fuse_tiles(const FuseArgs a) {
         facc[i] = 0.f;
         member[i] = 0;
     }
-    __shared__ uint32_t ns_sh;
+    __shared__ uint32_t mmu[4];  // min / max sparse score, min / max dense key (the lists come in any order)
     if (tid < 64) ss.cnt[tid] = 0;
     if (tid == 0) {
         ss.n_cand = 0;
         ss.tau0 = 1;
         ss.smax = 0;
-        ns_sh = 0;
+        mmu[0] = 0xFFFFFFFFu;
+        mmu[1] = 0;
+        mmu[2] = 0xFFFFFFFFu;
+        mmu[3] = 0;
     }
     __syncthreads();
-    for (uint32_t j = tid; j < a.depth; j += NT)
-        if (sk[j]) atomicMax(&ns_sh, j + 1);  // sparse hit count = index after the last non-empty slot
+    {
+        uint32_t lo_s = 0xFFFFFFFFu, hi_s = 0, lo_d = 0xFFFFFFFFu, hi_d = 0;
+        for (uint32_t j = tid; j < a.depth; j += NT) {
+            const uint64_t key = sk[j];
+            if (key) {
+                const uint32_t sc = (uint32_t)(key >> 32);
+                lo_s = min(lo_s, sc);
+                hi_s = max(hi_s, sc);
+            }
+            if ((int)j < dn) {
+                lo_d = min(lo_d, dk[j]);
+                hi_d = max(hi_d, dk[j]);
+            }
+        }
+        if (hi_s) {
+            atomicMin(&mmu[0], lo_s);
+            atomicMax(&mmu[1], hi_s);
+        }
+        if (hi_d) {
+            atomicMin(&mmu[2], lo_d);
+            atomicMax(&mmu[3], hi_d);
+        }
+    }
     __syncthreads();
     if (tid == 0) {
-        // lists are best-first: max = first entry, min = last non-empty entry
-        const uint32_t ns = ns_sh;
-        const float smax = ns ? (float)(uint32_t)(sk[0] >> 32) : 0.f, smin = ns ? (float)(uint32_t)(sk[ns - 1] >> 32) : 0.f;
-        const float dmax = dn > 0 ? key_to_f32(dk[0]) : 0.f, dmin = dn > 0 ? key_to_f32(dk[dn - 1]) : 0.f;
+        const bool has_s = mmu[1] != 0, has_d = mmu[3] != 0;  // (sparse scores and dense keys of hits are non-zero)
+        const float smax = has_s ? (float)mmu[1] : 0.f, smin = has_s ? (float)mmu[0] : 0.f;
+        const float dmax = has_d ? key_to_f32(mmu[3]) : 0.f, dmin = has_d ? key_to_f32(mmu[2]) : 0.f;
         mm[0] = smin;
         mm[1] = fmaxf(smax - smin, 1e-9f);
         mm[2] = dmin;
@@ -441,8 +466,10 @@ int msr_hybrid_search(msr_index* ix, msr_dense* dx, const int64_t* q_ptr, const 
         rc = MSR_E_NOMEM;
     }
     float t_gemm = 0, t_sel = 0, t_sparse = 0, t_merge = 0, t_fuse = 0;
+    // fuse_tiles takes both top-depth lists as SETS (min, max, membership): single-tile indexes skip the ranking
+    b->unsorted_ok = true;
     if (rc == MSR_OK) rc = batch_search_local(b, depth, false);  // sparse top-depth keys -> b->d_keys
-    if (rc == MSR_OK) rc = dense_search_impl(dx, q_fp16, nq, depth, d_didx, d_dkey, d_dn, &t_gemm, &t_sel, true);
+    if (rc == MSR_OK) rc = dense_search_impl(dx, q_fp16, nq, depth, d_didx, d_dkey, d_dn, &t_gemm, &t_sel, true, true);
     if (rc == MSR_OK) {
         (void)hipEventRecord(e0, d->stream);
         FuseArgs fa;
@@ -593,6 +620,7 @@ extern "C" int msr_sparsify(const void* logits, int is_f16, int fp16_math, int r
         hipLaunchKernelGGL(sparsify_keys, dim3(std::min<uint32_t>((vocab + 255) / 256, 1024), (uint32_t)rows), dim3(256), 0, st,
                            d_in, is_f16, fp16_math, d_keys, vocab, ld);
         SelectArgs se;
+        se.unsorted = 0;
         se.src = d_keys;
         se.part = d_part;
         se.n_docs = vocab;

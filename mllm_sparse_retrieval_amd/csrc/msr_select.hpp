@@ -166,6 +166,7 @@ struct TileLds {
 // Exact top-k of one accumulator tile held in LDS (shared by score_tiles and select_tiles).
 // Thread `tid` owns vec r*NT + tid of the accumulators in round r (conflict-free ds_read_b128); the accumulators are
 // re-read from LDS in every pass instead of being held in registers. Writes k keys best-first (0 = empty slot).
+// `unsorted`: the k keys may be written in any order (see the end of the function).
 // `hook_a` runs right after the first barrier and `hook_b` right after the candidate barrier (score_tiles issues the
 // next query's loads there, so that they are in flight during the rest of the selection); neither runs when the tile
 // matched nothing (early return).
@@ -176,7 +177,7 @@ template <int TILE_DOCS, int NT, int CAND, class Stamp, class HookA = NoHook, cl
 __device__ __forceinline__ void tile_select(const uint4* a4, uint64_t* cand, uint32_t* tmax, uint32_t* wmax,
                                             SelectScratch& ss, int rounds, uint64_t doc0, int k,
                                             uint64_t* __restrict__ out, Stamp stamp, const uint32_t tid,
-                                            HookA hook_a = HookA(), HookB hook_b = HookB()) {
+                                            HookA hook_a = HookA(), HookB hook_b = HookB(), const bool unsorted = false) {
     constexpr int NW = NT / 64;
     const uint32_t lane = tid & 63;
     const uint32_t wave = rfl(tid >> 6);
@@ -387,6 +388,11 @@ __device__ __forceinline__ void tile_select(const uint4* a4, uint64_t* cand, uin
             }
         __syncthreads();
         n_cand = min(ss.n_cand, (uint32_t)CAND);  // == min(k, #positive) <= CAND by construction
+    }
+    if (unsorted && n_cand <= (uint32_t)k) {
+        // the consumer takes the top-k as a SET (hybrid fusion: min / max / membership only): no ranking
+        for (int i = tid; i < k; i += NT) out[i] = i < (int)n_cand ? cand[i] : 0ull;
+        return;
     }
     rank_and_emit<NT, (CAND > 512)>(cand, (int)n_cand, k, out, tid);
 }
