@@ -363,13 +363,20 @@ __global__ __launch_bounds__(NT) void fuse_tiles(const FuseArgs a) {
                 hi_d = max(hi_d, dk[j]);
             }
         }
-        if (hi_s) {
-            atomicMin(&mmu[0], lo_s);
-            atomicMax(&mmu[1], hi_s);
-        }
-        if (hi_d) {
-            atomicMin(&mmu[2], lo_d);
-            atomicMax(&mmu[3], hi_d);
+        // wave reductions (DPP) first, then one LDS atomic per wave and quantity (min x = ~max ~x)
+        lo_s = ~wave_max_u32(~lo_s);
+        hi_s = wave_max_u32(hi_s);
+        lo_d = ~wave_max_u32(~lo_d);
+        hi_d = wave_max_u32(hi_d);
+        if ((tid & 63u) == 0) {
+            if (hi_s) {
+                atomicMin(&mmu[0], lo_s);
+                atomicMax(&mmu[1], hi_s);
+            }
+            if (hi_d) {
+                atomicMin(&mmu[2], lo_d);
+                atomicMax(&mmu[3], hi_d);
+            }
         }
     }
     __syncthreads();
