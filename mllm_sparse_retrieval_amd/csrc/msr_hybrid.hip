@@ -104,6 +104,95 @@ __global__ __launch_bounds__(256) void dense_scores(const _Float16* __restrict__
         }
 }
 
+
+// ---- the same product on a 256 x 256 block: 8 waves (2 x 4), each 128 x 64 = 4 x 2 MFMA tiles of 32 x 32 (six fragment
+// reads per eight MFMAs instead of four per four), K in steps of 64, two LDS stages of 2 x 32 KiB filled by LDS-DMA
+// (global_load_lds_dwordx4: no staging registers, no ds_write pass), one barrier per K step. The DMA writes LDS
+// lane-linear (wave-uniform base + 16 B x lane: eight 128-byte rows per instruction), so the bank swizzle goes on the
+// SOURCE address: the lane that fills 16-byte slot s of row `row` fetches the row's segment s ^ ((row >> 1) & 7), and
+// the fragment read of segment g of that row goes to slot g ^ ((row >> 1) & 7): 16 consecutive rows then touch 64
+// distinct banks. Used when the grid fills the chip (>= 256 blocks) and H % 64 == 0; otherwise the 128 x 128 kernel.
+constexpr int kG2Stage = 2 * 256 * 128;  // bytes per stage: A rows then B rows, 128 B (64 halves) each
+
+__global__ __launch_bounds__(512, 1) void dense_scores_256(const _Float16* __restrict__ Q, const _Float16* __restrict__ P,
+                                                           uint32_t* __restrict__ out, uint32_t M, uint32_t N, uint32_t H,
+                                                           uint64_t ld) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];  // 2 stages
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t r = lane & 31, h = lane >> 5;
+    const uint32_t q_blk = blockIdx.x * 256, d_blk = blockIdx.y * 256;
+    if (d_blk >= N) {  // padding docs that select_tiles still reads: keys 0
+        for (uint32_t i = tid; i < 256 * 64; i += 512) {
+            const uint32_t q = q_blk + i / 64;
+            if (q < M) reinterpret_cast<uint4*>(out + (uint64_t)q * ld + d_blk)[i % 64] = make_uint4(0, 0, 0, 0);
+        }
+        return;
+    }
+    const uint32_t wm = (wave >> 2) * 128, wn = (wave & 3) * 64;
+    float16v acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+    // LDS-DMA plan: instruction i of wave w fills rows 8c .. 8c+7 (c = 8i + w) of an operand; lane = (row in chunk, slot)
+    const _Float16* ga[4];
+    const _Float16* gb[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const uint32_t row = 8 * (8 * i + wave) + (lane >> 3);
+        const uint32_t seg = (lane & 7) ^ ((row >> 1) & 7);
+        ga[i] = Q + (uint64_t)(q_blk + row) * H + seg * 8;
+        gb[i] = P + (uint64_t)(d_blk + row) * H + seg * 8;
+    }
+    typedef __attribute__((address_space(3))) void lds_void;
+    typedef const __attribute__((address_space(1))) void glb_void;
+    auto issue = [&](int stage, uint32_t k0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            uint8_t* const da = smem + stage * kG2Stage + (8 * i + wave) * 1024;
+            __builtin_amdgcn_global_load_lds((glb_void*)(ga[i] + k0), (lds_void*)da, 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((glb_void*)(gb[i] + k0), (lds_void*)(da + 256 * 128), 16, 0, 0);
+        }
+    };
+    const uint32_t f = (r >> 1) & 7;  // swizzle of this lane's fragment rows ((wm + 32 i + r) >> 1) & 7 == (r >> 1) & 7
+    const uint32_t fa = (wm + r) * 128, fb = 256 * 128 + (wn + r) * 128;
+    const uint32_t KT = H / 64;
+    issue(0, 0);
+    for (uint32_t kt = 0; kt < KT; ++kt) {
+        const int cur = (int)(kt & 1);
+        __syncthreads();  // (hipcc drains the DMA with vmcnt(0) first) stage `cur` is filled, stage cur^1 is free again
+        if (kt + 1 < KT) issue(cur ^ 1, (kt + 1) * 64);
+        const uint8_t* const st = smem + cur * kG2Stage;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            const uint32_t slot = ((2 * kk + h) ^ f) * 16;
+            half8 a[4], b[2];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) a[i] = *reinterpret_cast<const half8*>(st + fa + i * 32 * 128 + slot);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) b[j] = *reinterpret_cast<const half8*>(st + fb + j * 32 * 128 + slot);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+    }
+    // C/D map of the 32x32 shapes: column = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const uint32_t d = d_blk + wn + 32 * j + r;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const uint32_t q = q_blk + wm + 32 * i + (e & 3) + 8 * (e >> 2) + 4 * h;
+                if (q < M) out[(uint64_t)q * ld + d] = d < N ? f32_to_key(acc[i][j][e]) : 0u;
+            }
+        }
+}
+
 }  // namespace msr
 
 struct msr_dense {
@@ -180,9 +269,9 @@ static int dense_search_impl(msr_dense* dx, const uint16_t* q_fp16, int nq, int 
         return MSR_E_RANGE;
     }
     HIP_TRY(hipSetDevice(dx->device));
-    const uint32_t QT = 8192;  // queries per pass: scores buffer QT x n_pad u32
+    const uint32_t QT = 32768;  // queries per pass: scores buffer QT x n_pad u32 (1 GiB at 8192 padded docs)
     const uint32_t qt = (uint32_t)std::min<uint32_t>(QT, std::max(nq, 1));
-    const uint32_t qt_pad = (qt + 127) / 128 * 128;
+    const uint32_t qt_pad = (qt + 255) / 256 * 256;
     _Float16* d_Q = nullptr;
     uint32_t* d_S = nullptr;
     uint64_t *d_part = nullptr;
@@ -205,7 +294,7 @@ static int dense_search_impl(msr_dense* dx, const uint16_t* q_fp16, int nq, int 
     double t_gemm = 0, t_sel = 0;
     for (int q0 = 0; q0 < nq && rc == MSR_OK; q0 += (int)qt) {
         const uint32_t qn = (uint32_t)std::min<int>((int)qt, nq - q0);
-        const uint32_t qn_pad = (qn + 127) / 128 * 128;
+        const uint32_t qn_pad = (qn + 255) / 256 * 256;
         bool c = hipMemsetAsync(d_Q, 0, (size_t)qn_pad * dx->h * 2, dx->stream) == hipSuccess &&
                  hipMemcpyAsync(d_Q, q_fp16 + (size_t)q0 * dx->h, (size_t)qn * dx->h * 2, hipMemcpyHostToDevice,
                                 dx->stream) == hipSuccess &&
@@ -219,8 +308,19 @@ static int dense_search_impl(msr_dense* dx, const uint16_t* q_fp16, int nq, int 
         // the select instance: 1024 docs at 4096-doc tiles, 2048 at 8192); padding beyond that is never read
         const uint64_t round_docs = dx->tile_docs == 4096 ? 1024 : 2048;
         const uint64_t n_cover = std::min<uint64_t>(dx->n_pad, (dx->n + round_docs - 1) / round_docs * round_docs);
-        hipLaunchKernelGGL(dense_scores, dim3(qn_pad / 128, (uint32_t)(n_cover / 128)), dim3(256), 0, dx->stream, d_Q,
-                           dx->d_P, d_S, qn, (uint32_t)dx->n, dx->h, dx->n_pad);
+        if (dx->h % 64 == 0 && n_cover % 256 == 0 && (uint64_t)(qn_pad / 256) * (n_cover / 256) >= 256) {
+            static bool lds_set = false;  // 128 KiB of dynamic LDS needs the opt-in (once per process)
+            if (!lds_set) {
+                HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(dense_scores_256),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, 2 * kG2Stage));
+                lds_set = true;
+            }
+            hipLaunchKernelGGL(dense_scores_256, dim3(qn_pad / 256, (uint32_t)(n_cover / 256)), dim3(512), 2 * kG2Stage,
+                               dx->stream, d_Q, dx->d_P, d_S, qn, (uint32_t)dx->n, dx->h, dx->n_pad);
+        } else {
+            hipLaunchKernelGGL(dense_scores, dim3(qn_pad / 128, (uint32_t)(n_cover / 128)), dim3(256), 0, dx->stream, d_Q,
+                               dx->d_P, d_S, qn, (uint32_t)dx->n, dx->h, dx->n_pad);
+        }
         (void)hipEventRecord(e1, dx->stream);
         SelectArgs se;
         se.unsorted = 0;

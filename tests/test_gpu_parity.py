@@ -376,7 +376,9 @@ def _dense_oracle(q, p, k):
     return np.take_along_axis(s, order, axis=1), order
 
 
-@pytest.mark.parametrize("n,h,nq,k", [(5000, 256, 300, 1000), (700, 64, 130, 10), (20000, 128, 64, 100), (3, 16, 5, 10)])
+# (the third-last case fills >= 256 blocks of 256 x 256: the LDS-DMA GEMM kernel; the others take the 128 x 128 one)
+@pytest.mark.parametrize("n,h,nq,k", [(5000, 256, 300, 1000), (700, 64, 130, 10), (20000, 128, 64, 100), (3, 16, 5, 10),
+                                      (4200, 192, 4100, 10), (9000, 64, 2100, 100)])
 def test_dense_search_against_numpy(m, n, h, nq, k):
     from mllm_sparse_retrieval_amd.dense import FaissFlatSearcher
 
