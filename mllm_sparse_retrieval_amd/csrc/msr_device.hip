@@ -73,7 +73,10 @@ int launch_select(hipStream_t st, uint32_t tile_docs, const SelectArgs& a) {
 
 int launch_merge(hipStream_t st, const MergeArgs& a) {
     if (a.nq == 0) return MSR_OK;
-    hipLaunchKernelGGL((merge_lists<256>), dim3(a.nq), dim3(256), 0, st, a);
+    if ((uint64_t)a.n_lists * a.k <= 64 && a.k <= 64)
+        hipLaunchKernelGGL(merge_small, dim3((a.nq + 3) / 4), dim3(256), 0, st, a);  // one wave per query
+    else
+        hipLaunchKernelGGL((merge_lists<256>), dim3(a.nq), dim3(256), 0, st, a);
     HIP_TRY(hipGetLastError());
     return MSR_OK;
 }
