@@ -83,15 +83,21 @@ __global__ __launch_bounds__(NT, MIN_WAVES) void score_tiles(const ScoreArgs a) 
         make_rsrc(reinterpret_cast<const char*>(a.postings) + (uint64_t)(tile_first - a.vec_base) * 16u,
                   (seg_row[a.n_terms] - tile_first) * 16u);
 
-    // ---- first round's (term -> segment) lookups: two dependent global loads, issued before the zeroing so that
-    // their latency hides behind it
-    uint32_t pre_w = 0, pre_s0 = 0, pre_s1 = 0;
-    if (tid < min((uint32_t)kQtBlock, qe - qb)) {
-        const uint32_t t = a.q_term[qb + tid];
+    // ---- first round's (term -> segment) lookups: two dependent global loads. The first (terms, weights) goes out
+    // now; the second (segment pointers) needs the terms, so it is issued AFTER the first dense rows have been
+    // requested — otherwise the wait for the terms would hold the rows back by a round trip.
+    uint32_t pre_t = 0, pre_w = 0, pre_s0 = 0, pre_s1 = 0;
+    const bool has_lk = tid < min((uint32_t)kQtBlock, qe - qb);
+    if (has_lk) {
+        pre_t = a.q_term[qb + tid];
         pre_w = a.q_w[qb + tid];
-        pre_s0 = seg_row[t];
-        pre_s1 = seg_row[t + 1];
     }
+    auto lookup2 = [&]() {
+        if (has_lk) {
+            pre_s0 = seg_row[pre_t];
+            pre_s1 = seg_row[pre_t + 1];
+        }
+    };
 
     // ---- initialise the accumulators: zero, or — when the query holds dense-head terms — their whole contribution.
     // Thread `tid` owns vecs r*NT + tid (4 consecutive docs each); the dense head is doc-major, one dword per doc and
@@ -135,6 +141,7 @@ __global__ __launch_bounds__(NT, MIN_WAVES) void score_tiles(const ScoreArgs a) 
                 uint32_t pa = (uint32_t)__builtin_ctz(m), pb = 0;
                 m &= m - 1;
                 load_rows(xa, pa);
+                if (r0 == 0) lookup2();
                 for (;;) {
                     const bool more_b = m != 0;
                     if (more_b) {
@@ -158,6 +165,7 @@ __global__ __launch_bounds__(NT, MIN_WAVES) void score_tiles(const ScoreArgs a) 
             for (int i = 0; i < RG; ++i)
                 if (r0 + i < rounds) a4[(r0 + i) * NT + tid] = sacc[i];
         }
+        if (!pmask) lookup2();  // (no dense rows were requested)
     }
     if (tid < 64) ss.cnt[tid] = 0;
     if (tid == 0) {
