@@ -325,7 +325,7 @@ __global__ __launch_bounds__(NT, MIN_WAVES) void score_tiles(const ScoreArgs a) 
         stamp(6);
         return;
     }
-    tile_select<TILE_DOCS, NT, CAND>(a4, cand, tmax, wmax, ss, rounds, doc0, k, out, stamp, tid, NoHook(), NoHook(),
+    tile_select<TILE_DOCS, NT, CAND>(a4, cand, tmax, wmax, ss, rounds, doc0, k, out, stamp, tid,
                                      a.unsorted != 0);
     stamp(6);  // ranking + output
 }
@@ -365,8 +365,8 @@ __global__ __launch_bounds__(NT) void select_tiles(const SelectArgs a) {
         ss.smax = 0;
     }
     __syncthreads();
-    tile_select<TILE_DOCS, NT, CAND>(a4, cand, tmax, wmax, ss, rounds, doc0, (int)a.k, out, [](int) {}, tid, NoHook(),
-                                     NoHook(), a.unsorted != 0);
+    tile_select<TILE_DOCS, NT, CAND>(a4, cand, tmax, wmax, ss, rounds, doc0, (int)a.k, out, [](int) {}, tid,
+                                     a.unsorted != 0);
 }
 
 // ------------------------------------------------------------------------------------------------ kernel 2

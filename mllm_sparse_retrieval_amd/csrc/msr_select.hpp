@@ -167,17 +167,11 @@ struct TileLds {
 // Thread `tid` owns vec r*NT + tid of the accumulators in round r (conflict-free ds_read_b128); the accumulators are
 // re-read from LDS in every pass instead of being held in registers. Writes k keys best-first (0 = empty slot).
 // `unsorted`: the k keys may be written in any order (see the end of the function).
-// `hook_a` runs right after the first barrier and `hook_b` right after the candidate barrier (score_tiles issues the
-// next query's loads there, so that they are in flight during the rest of the selection); neither runs when the tile
-// matched nothing (early return).
-struct NoHook {
-    __device__ __forceinline__ void operator()() const {}
-};
-template <int TILE_DOCS, int NT, int CAND, class Stamp, class HookA = NoHook, class HookB = NoHook>
+template <int TILE_DOCS, int NT, int CAND, class Stamp>
 __device__ __forceinline__ void tile_select(const uint4* a4, uint64_t* cand, uint32_t* tmax, uint32_t* wmax,
                                             SelectScratch& ss, int rounds, uint64_t doc0, int k,
                                             uint64_t* __restrict__ out, Stamp stamp, const uint32_t tid,
-                                            HookA hook_a = HookA(), HookB hook_b = HookB(), const bool unsorted = false) {
+                                            const bool unsorted = false) {
     constexpr int NW = NT / 64;
     const uint32_t lane = tid & 63;
     const uint32_t wave = rfl(tid >> 6);
@@ -196,7 +190,6 @@ __device__ __forceinline__ void tile_select(const uint4* a4, uint64_t* cand, uin
     if ((lane & (G - 1)) == 0) wmax[tid / G] = gm;
     if (k > 64) tmax[tid] = mymax;
     __syncthreads();
-    hook_a();
 
     uint32_t tau0 = 1, smax;
     {
@@ -259,7 +252,6 @@ __device__ __forceinline__ void tile_select(const uint4* a4, uint64_t* cand, uin
     __syncthreads();
     stamp(5);  // candidate collection
     uint32_t n_cand = ss.n_cand;
-    hook_b();
 
     if (n_cand > CAND) {
         // ---- fallback (mass ties, or k in the hundreds): exact selection by radix passes over the score.
