@@ -495,8 +495,10 @@ __global__ __launch_bounds__(NT) void merge_lists(const MergeArgs a) {
             __syncthreads();
             return ss.n_cand;
         };
-        uint32_t got = kCandCap + 1;
-        if (a.n_lists >= (uint32_t)k) {
+        // The lists of a staged search are mostly EMPTY (tiles of the second stage report only keys at or above the
+        // query's threshold): when all non-empty keys fit the buffer, take them as they are — no threshold search.
+        uint32_t got = collect(1);  // every non-zero key (collect() stops storing at kCandCap but keeps counting)
+        if (got > kCandCap && a.n_lists >= (uint32_t)k) {
             const uint64_t tau_heads = bisect_kth(a.n_lists, [&](uint32_t l) { return key_at(l * a.k); });
             if (tau_heads) got = collect(tau_heads);
         }
