@@ -79,9 +79,7 @@ __global__ __launch_bounds__(NT, MIN_WAVES) void score_tiles(const ScoreArgs a) 
     // arithmetic per chunk (the scalar ALU is shared by the CU's 32 waves), no zero-extended offset pairs in VGPRs,
     // and a read past the tile's postings returns 0 instead of faulting.
     const uint32_t tile_first = seg_row[0];
-    const __amdgpu_buffer_rsrc_t rs_post =
-        make_rsrc(reinterpret_cast<const char*>(a.postings) + (uint64_t)(tile_first - a.vec_base) * 16u,
-                  (seg_row[a.n_terms] - tile_first) * 16u);
+    const char* const post_base = reinterpret_cast<const char*>(a.postings) + (uint64_t)(tile_first - a.vec_base) * 16u;
 
     // ---- first round's (term -> segment) lookups: two dependent global loads. The first (terms, weights) goes out
     // now; the second (segment pointers) needs the terms, so it is issued AFTER the first dense rows have been
@@ -253,9 +251,11 @@ __global__ __launch_bounds__(NT, MIN_WAVES) void score_tiles(const ScoreArgs a) 
                         v[u] = make_uint4((1u << 16) | (hsh >> 17), (1u << 16) | ((hsh * 31u) >> 17),
                                           (1u << 16) | ((hsh * 131u) >> 17), (1u << 16) | ((hsh * 1031u) >> 17));
                     } else {
-                        // lanes past the chunk's end re-read its last vec (same cache line); an idle slot (n16 = 0:
-                        // the clamp wraps to 2^32 - 16) reads the tile's first vecs; all inside the tile or zero
-                        v[u] = buf_load16(rs_post, min(lane16, n16 - 16u), b16);
+                        // The chunk's END offset goes into the resource's size word: the buffer range check compares
+                        // scalar + lane offset with it, so lanes past the chunk's end — and every lane of an idle
+                        // slot — get zeros without a memory request, with no clamp instruction; the lane offset is
+                        // the loop-invariant lane16.
+                        v[u] = buf_load16(make_rsrc(post_base, b16 + n16), lane16, b16);
                     }
                 }
             };
