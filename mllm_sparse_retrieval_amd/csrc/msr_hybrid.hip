@@ -269,7 +269,8 @@ static int dense_search_impl(msr_dense* dx, const uint16_t* q_fp16, int nq, int 
         return MSR_E_RANGE;
     }
     HIP_TRY(hipSetDevice(dx->device));
-    const uint32_t QT = 32768;  // queries per pass: scores buffer QT x n_pad u32 (1 GiB at 8192 padded docs)
+    // queries per pass: the score buffer holds qt x n_pad u32 keys and is capped at 4 GiB (1 GiB at 8192 padded docs)
+    const uint32_t QT = (uint32_t)std::min<uint64_t>(32768, std::max<uint64_t>(256, ((1ull << 30) / std::max<uint64_t>(dx->n_pad, 1)) / 256 * 256));
     const uint32_t qt = (uint32_t)std::min<uint32_t>(QT, std::max(nq, 1));
     const uint32_t qt_pad = (qt + 255) / 256 * 256;
     _Float16* d_Q = nullptr;
