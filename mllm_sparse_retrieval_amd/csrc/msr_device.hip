@@ -559,7 +559,9 @@ int batch_search_local(msr_batch* b, int k, bool final_arrays) {
     const uint32_t nt = ix->shard_ntiles;
     static const int stage_env = getenv("MSR_STAGE1_TILES") ? atoi(getenv("MSR_STAGE1_TILES")) : -1;
     uint32_t t1 = nt;
-    if (nt >= 2 && !sa.dbg && stage_env != 0)
+    // (small launches — fewer (tile, query) pairs than one round of resident workgroups — stay in ONE launch: two
+    // more kernels in the chain would cost the call more latency than the cheaper selection saves)
+    if (nt >= 2 && !sa.dbg && stage_env != 0 && (stage_env > 0 || (uint64_t)nt * (uint64_t)b->nq >= kMinStagedPairs))
         t1 = stage_env > 0 ? std::min<uint32_t>(nt, (uint32_t)stage_env) : std::max<uint32_t>(1u, nt / kStage1Fraction);
     sa.theta = nullptr;
     sa.unsorted = (b->unsorted_ok && nt == 1) ? 1u : 0u;  // one tile: its list IS the query's list

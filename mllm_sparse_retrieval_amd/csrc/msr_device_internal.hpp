@@ -28,6 +28,7 @@ namespace msr {
 constexpr int kQtBlock = 256;    // query terms staged in LDS per round
 constexpr int kCandCap = 1024;   // candidate keys per workgroup (>= MSR_KMAX)
 constexpr uint32_t kMaxGridY = 65535;  // HIP grid limit in y (tiles per launch)
+constexpr uint64_t kMinStagedPairs = 4096;  // ... and only launches with at least this many (tile, query) pairs are staged
 constexpr uint32_t kStage1Fraction = 16;  // staged search: 1/16 of the tiles (at least one) set the thresholds
 constexpr int kChunkVecs = 64;   // one chunk = one wave-wide uint4 load = 256 postings = 1 KiB
 static_assert(kCandCap >= MSR_KMAX, "candidate buffer must hold k keys");

@@ -308,6 +308,7 @@ def test_staged_search_thresholds(m, tmp_path):
     finally:
         m.set_build_option("dense_max_terms", 16)
     queries = [[(0, 3)], [(1, 2)], [(2, 9)], [(3, 1), (2, 1)], [(4, 1)], [(1, 1), (3, 2), (5, 7)], [(0, 1), (2, 1)]]
+    queries = queries * 40  # 280 queries x 20 tiles: above the library's minimum of (tile, query) pairs for staging
     qp = np.cumsum([0] + [len(q) for q in queries]).astype(np.int64)
     qt = np.array([t for q in queries for t, _ in q], dtype=np.int32)
     qw = np.array([w for q in queries for _, w in q], dtype=np.int32)
