@@ -182,9 +182,11 @@ void device_detach(msr_index* ix) {
     DeviceIndex* d = ix->dev;
     if (!d) return;
     (void)hipSetDevice(d->device);
+    if (d->stream) (void)hipStreamSynchronize(d->stream);  // nothing may still read the staging buffer or the index
     if (d->comm) ncclCommDestroy(d->comm);
     d->pool.purge();
     for (hipEvent_t e : d->spare_events) (void)hipEventDestroy(e);
+    if (d->stage_ev) (void)hipEventDestroy(d->stage_ev);
     if (d->h_stage) (void)hipHostFree(d->h_stage);
     if (d->d_seg_ptr) (void)hipFree(d->d_seg_ptr);
     if (d->d_postings) (void)hipFree(d->d_postings);
@@ -443,6 +445,10 @@ static int batch_create_impl(msr_index* ix, const int64_t* q_ptr, const int32_t*
         const size_t in_bytes = in_words * 4;
         bool ok = true;
         if (in_bytes <= (8u << 20)) {
+            if (d->stage_pending) {  // an earlier batch's upload may still be reading the staging buffer
+                (void)hipEventSynchronize(d->stage_ev);
+                d->stage_pending = false;
+            }
             if (d->h_stage_bytes < in_bytes) {
                 if (d->h_stage) (void)hipHostFree(d->h_stage);
                 d->h_stage = nullptr;
@@ -459,9 +465,13 @@ static int batch_create_impl(msr_index* ix, const int64_t* q_ptr, const int32_t*
                 memcpy(hs + o_w, qw.data(), qw.size() * 4);
             }
             if (!qdense.empty()) memcpy(hs + o_dense, qdense.data(), qdense.size() * 4);
-            // synchronous on purpose: the staging buffer is reused by the next call
-            ok = hipMemcpyAsync(d_in, hs, in_bytes, hipMemcpyHostToDevice, d->stream) == hipSuccess &&
-                 hipStreamSynchronize(d->stream) == hipSuccess;
+            // asynchronous: the kernels follow on the same stream; the event guards the staging buffer's next use
+            if (!d->stage_ev && hipEventCreateWithFlags(&d->stage_ev, hipEventDisableTiming) != hipSuccess) d->stage_ev = nullptr;
+            ok = hipMemcpyAsync(d_in, hs, in_bytes, hipMemcpyHostToDevice, d->stream) == hipSuccess;
+            if (ok && d->stage_ev && hipEventRecord(d->stage_ev, d->stream) == hipSuccess)
+                d->stage_pending = true;
+            else
+                ok = ok && hipStreamSynchronize(d->stream) == hipSuccess;
         } else {
             ok = hipMemcpy(b->d_qptr, qptr.data(), qptr.size() * 4, hipMemcpyHostToDevice) == hipSuccess &&
                  (qterm.empty() || (hipMemcpy(b->d_qterm, qterm.data(), qterm.size() * 4, hipMemcpyHostToDevice) == hipSuccess &&
@@ -642,6 +652,7 @@ int msr_batch_fetch(msr_batch* b, uint32_t* out_doc_ord, float* out_score, uint3
         if (n && d->h_stage && span * 4 <= d->h_stage_bytes) {
             HIP_TRY(hipMemcpyAsync(d->h_stage, b->d_ord, span * 4, hipMemcpyDeviceToHost, d->stream));
             HIP_TRY(hipStreamSynchronize(d->stream));
+            d->stage_pending = false;  // (everything queued on the stream, uploads included, is done)
             const uint32_t* hs = (const uint32_t*)d->h_stage;
             if (out_doc_ord) memcpy(out_doc_ord, hs, n * 4);
             if (out_score_u32) memcpy(out_score_u32, hs + (b->d_su32 - b->d_ord), n * 4);

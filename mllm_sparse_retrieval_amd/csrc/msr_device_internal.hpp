@@ -82,6 +82,8 @@ struct DeviceIndex {
     std::vector<hipEvent_t> spare_events;  // recycled by the batches of this handle
     void* h_stage = nullptr;               // pinned staging for small uploads / downloads
     size_t h_stage_bytes = 0;
+    hipEvent_t stage_ev = nullptr;         // recorded after an async upload out of h_stage ...
+    bool stage_pending = false;            // ... and waited for before the buffer is written or freed again
     uint32_t* d_seg_ptr = nullptr;   // [shard_ntiles][n_terms+1] absolute vec index
     uint32_t* d_postings = nullptr;  // the shard's vecs; vec v of the index lives at d_postings + (v - vec_base)*4
     uint32_t* d_dense = nullptr;     // [shard_ntiles][n_pairs][tile_docs] dense head of the shard's tiles
