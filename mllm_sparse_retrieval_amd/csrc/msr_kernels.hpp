@@ -1,17 +1,21 @@
-// The search-path kernels (included by msr_device.hip only). Roofline class: HBM; no MFMA — this is
-// gather + integer reduce.
+// The search-path kernels (included by msr_device.hip only). Roofline class: HBM by the task's definition (SURVEY.md
+// §8d); no MFMA — this is gather + integer reduce, and what it actually runs into is VALU issue and the L2 -> CU path
+// (DESIGN.md §7).
 //
-// score_tiles<TILE_DOCS, NT, U, MIN_WAVES, CAND, DBG, MODE>   one workgroup per (doc tile, query)
+// score_tiles<TILE_DOCS, NT, U, MIN_WAVES, CAND, DBG, MODE>   one workgroup per (doc tile, query); grid = (query, tile)
 //     - TILE_DOCS u32 accumulators in LDS (32 KiB at the default 8192 docs: four workgroups = 32 waves per CU),
 //     - dense-head terms: doc-major rows scored by the accumulator's owner with v_dot2_u32_u16 (this is also the
 //       accumulator init),
 //     - the query's other (term, tile) segments are cut into 1-KiB chunks (64 lanes x 16 B = 256 postings); waves take
-//       chunks round-robin, resolve 64 chunks lane-parallel, then walk them with v_readlane broadcasts: one uint4 load
-//       and four ds_add_u32 per lane and chunk, two register banks in flight,
-//     - exact per-tile top-k (tile_select, msr_select.hpp).
-//     Workgroups are ordered tile-major, so the ~1000 workgroups in flight score the SAME tile for different queries
-//     and the tile's rows and hot segments are served from the XCDs' L2s, not from HBM.
+//       chunks round-robin, resolve 64 chunks lane-parallel, then walk them with v_readlane broadcasts: one 16-byte
+//       buffer load (chunk end in the resource's size word) and four ds_add_u32 per lane and chunk, two register
+//       banks in flight,
+//     - exact per-tile top-k: tile_select, or theta_select when an earlier launch's tiles gave the query a threshold
+//       (staged search, msr_device.hip) — both in msr_select.hpp.
+//     x (query) runs fastest in dispatch order, so the ~1000 workgroups in flight score the SAME tile for different
+//     queries and the tile's rows and hot segments are served from the XCDs' L2s, not from HBM.
 // select_tiles   top-k of an accumulator tile that already sits in HBM (term shards, dense scores, sparsifier).
+// merge_small    one WAVE per query: exact top-k of at most 64 keys (a few tiles x small k).
 // merge_lists    one workgroup per query: exact top-k of best-first lists (per tile or per shard).
 #pragma once
 
