@@ -1315,23 +1315,38 @@ static void encode_query_strings(const msr_index* ix, const char* const* queries
     for (int i = 0; i < nq; ++i) {
         slot.clear();
         const char* p = queries[i] ? queries[i] : "";
+        // The reference writes a token `weight` times IN A ROW (src/search.py:419-422): a token equal to its
+        // predecessor bumps the same slot without touching the hash map.
+        const char* prev_b = nullptr;
+        size_t prev_len = 0;
+        int32_t prev_slot = -1;
         while (*p) {
             while (*p && is_space((unsigned char)*p)) ++p;
             const char* b = p;
             while (*p && !is_space((unsigned char)*p)) ++p;
             if (p == b) break;
+            const size_t len = (size_t)(p - b);
+            if (prev_b && len == prev_len && memcmp(b, prev_b, len) == 0) {
+                if (prev_slot >= 0 && q_w[(size_t)prev_slot] < INT32_MAX) q_w[(size_t)prev_slot]++;
+                continue;
+            }
+            prev_b = b;
+            prev_len = len;
             tok.assign(b, p);
             auto it = slot.find(tok);
             if (it != slot.end()) {
+                prev_slot = it->second;
                 if (it->second >= 0 && q_w[(size_t)it->second] < INT32_MAX) q_w[(size_t)it->second]++;
                 continue;
             }
             const int32_t tid = ix->host.lookup(tok.c_str());
             if (tid < 0) {
                 slot.emplace(tok, -1);  // out of vocabulary: remember, so that repeats cost one hash probe
+                prev_slot = -1;
                 continue;
             }
-            slot.emplace(tok, (int32_t)q_term.size());
+            prev_slot = (int32_t)q_term.size();
+            slot.emplace(tok, prev_slot);
             q_term.push_back(tid);
             q_w.push_back(1);
         }
