@@ -108,6 +108,38 @@ def device_sync():
         pass
 
 
+_HBM_COPY_GBS = None
+
+
+def hbm_copy_gbs():
+    """Measured HBM bandwidth of a device-to-device copy on this rank's GPU (read + write bytes / time), quoted beside
+    the vendor peak as SURVEY.md §8d asks. torch is only the allocator and the timer here."""
+    global _HBM_COPY_GBS
+    if _HBM_COPY_GBS is None:
+        try:
+            import torch
+
+            dev = torch.device("cuda", _SYNC_DEVICE if isinstance(_SYNC_DEVICE, int) else 0)
+            n = 1 << 30
+            a = torch.empty(n, dtype=torch.uint8, device=dev)
+            b = torch.empty(n, dtype=torch.uint8, device=dev)
+            a.zero_()
+            for _ in range(2):
+                b.copy_(a)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            reps = 8
+            for _ in range(reps):
+                b.copy_(a)
+            e1.record()
+            torch.cuda.synchronize(dev)
+            _HBM_COPY_GBS = round(2.0 * n * reps / (e0.elapsed_time(e1) * 1e-3) / 1e9, 1)
+            del a, b
+        except Exception:
+            _HBM_COPY_GBS = 0.0
+    return _HBM_COPY_GBS or None
+
+
 def timed_steps(batch, k, steps, warmup, ranks, sharded=False, step=None):
     """`step` (optional) replaces batch.search for exchanges that run on the host (gloo fallback)."""
     run = step if step is not None else (lambda: batch.search(k, sharded=sharded))
@@ -149,7 +181,7 @@ def roofline(batch, k, score_ms_avg, workload_name):
     return {"bound": "hbm", "kernel": "score_tiles", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
             "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
             "algorithmic_bytes_per_launch": by, "postings_per_launch": postings,
-            "kernel_ms": round(score_ms_avg, 4), "launches_per_step": 2 if batch.index.n_tiles >= 2 else 1,
+            "hbm_copy_measured": hbm_copy_gbs(), "kernel_ms": round(score_ms_avg, 4), "launches_per_step": 2 if batch.index.n_tiles >= 2 else 1,
             "note": "achieved = SURVEY §8d algorithmic bytes / kernel time; it can exceed the HBM peak because a tile's "
                     "postings are re-read by every query from the XCDs' L2, not from HBM (traffic = measured HBM-side "
                     "bytes per step); the kernel's own limiters are VALU issue (64-74 % busy) and L2->CU bandwidth "
