@@ -223,6 +223,8 @@ def cpu_baseline(wl, got, target_seconds, threads):
                 break
     except OSError:
         pass
+    # (one thread count only: the 1-GPU box grants this job 16 CPUs, which is also the reference's setting,
+    # scripts/search_sparse.sh:17 — 128 threads on the same share measured SLOWER, 202 K vs 231 K q/s)
     return {"value": round(n / dt_s, 1), "unit": "queries/s", "cores": threads, "kind": "port",
             "cpu_model": cpu_model, "host_logical_cpus": os.cpu_count(),
             "sample": f"first {n} of {nq} queries of the same workload, {threads} threads, exhaustive term-at-a-time "
