@@ -55,6 +55,18 @@ def test_coco_shape_c3_depth1000(m, tmp_path):
     _case(m, tmp_path, 5000, 128, 300, 120, 30000, seed=2, tile_docs=0, ks=[10, 1000])
 
 
+def test_coco_shape_c3_image_to_text_full(m, tmp_path):
+    # BASELINE config 3, image->text direction at its real shape: 25 010 caption docs (4 tiles of 8192, the default
+    # tile), ALL 5 000 image queries x 120 nnz, V = 30 000; top-10 (scripts/search_sparse.sh:22) and the hybrid
+    # script's depth 1000 (scripts/search.sh:25), every query against the C oracle
+    _case(m, tmp_path, 25010, 128, 5000, 120, 30000, seed=2, tile_docs=0, ks=[10, 1000])
+
+
+def test_coco_shape_c3_text_to_image_full(m, tmp_path):
+    # ... and the text->image direction with all 25 010 caption queries against 5 000 image docs (one tile)
+    _case(m, tmp_path, 5000, 128, 25010, 120, 30000, seed=3, tile_docs=0, ks=[10])
+
+
 def test_many_query_terms(m, tmp_path):
     # > 256 terms per query exercises the staged term rounds
     _case(m, tmp_path, 9000, 32, 50, 700, 4000, seed=5, tile_docs=4096, ks=[10, 37])
@@ -244,16 +256,18 @@ def test_cli_search_end_to_end(m, tmp_path, capsys):
 
 
 # ------------------------------------------------------------------------------------------------ full-size properties
-def test_full_size_properties_c4(m, tmp_path):
+@pytest.mark.parametrize("tile_docs,n_tiles", [(32768, 31), (0, 123)])
+def test_full_size_properties_c4(m, tmp_path, tile_docs, n_tiles):
     """BASELINE config 4 size (1 M docs, 128 M postings): size-independent properties instead of a full oracle run,
-    plus an oracle check on a query sample."""
+    plus an oracle check on a query sample. tile_docs = 0 is the production instance bench.py runs (8192-doc tiles,
+    123 tiles, staged search with 7 first-stage tiles)."""
     n_docs, n_terms, nq = 1_000_000, 30000, 2000
     docs = m.synth_vectors(n_docs, 128, n_terms, seed=3, threads=16)
     qp, qt, qw = m.synth_vectors(nq, 120, n_terms, seed=4, threads=16)
     qp, qt, qw = qp.astype(np.int64), qt.astype(np.int32), qw.astype(np.int32)
-    path = m.build_index_from_csr(str(tmp_path / "c4.idx"), *docs, n_terms, tile_docs=32768)
+    path = m.build_index_from_csr(str(tmp_path / "c4.idx"), *docs, n_terms, tile_docs=tile_docs)
     with m.SparseIndex(path, device=0) as ix:
-        assert ix.n_tiles == 31 and ix.n_postings == 128_000_000
+        assert ix.n_tiles == n_tiles and ix.n_postings == 128_000_000
         o, f, u, n = ix.search_csr(qp, qt, qw, 10)
         assert (n == 10).all()
         assert (np.diff(u.astype(np.int64), axis=1) <= 0).all()                       # sorted by score
@@ -484,6 +498,66 @@ def test_gpu_fusion_matches_host_fuse(m, tmp_path, n, alpha, remove):
                 assert abs(float(want[qid][got_ids[i][j]]) - float(score)) <= 2e-6
         if remove:
             assert qid not in got_ids[i]
+
+
+def test_c5_real_shape_dense_and_hybrid_vs_oracle_pipeline(m, tmp_path):
+    """BASELINE config 5 at its REAL shape (scripts/search.sh:25,32): N = 5 000 docs x (128 nnz + 4096-d fp16), 25 010
+    queries x (120 nnz + 4096-d), depth 1000 -> fused top-10, alpha 0.5. All queries run on the GPU (the 256 x 256
+    LDS-DMA GEMM instance, K = 4096 accumulation); a sample of every 25th query is checked against
+      (a) dense: numpy f32 inner products of the fp16-rounded inputs, top-1000, scores within 1e-5,
+      (b) hybrid: the ORACLE pipeline — C oracle sparse top-1000 + numpy dense top-1000 -> oracle.get_run_dict ->
+          oracle.fuse (pinned to src/hybrid.py:32-53) -> top-10 — fused scores within 1e-5, ids equal up to near-ties."""
+    from mllm_sparse_retrieval_amd.dense import DenseIndex, hybrid_search, row_to_ordinal
+    from oracle import oracle
+
+    n, nq, h, depth, k, alpha, n_terms = 5000, 25010, 4096, 1000, 10, 0.5, 30000
+    docs = m.synth_vectors(n, 128, n_terms, seed=4, threads=16)
+    qp, qt, qw = m.synth_vectors(nq, 120, n_terms, seed=5, threads=16)
+    qp, qt, qw = qp.astype(np.int64), qt.astype(np.int32), qw.astype(np.int32)
+    rng = np.random.default_rng(4)
+    p, q = _unit_rows(rng, n, h), _unit_rows(rng, nq, h)
+    ids = [str(i) for i in range(n)]
+    path = m.build_index_from_csr(str(tmp_path / "c5.idx"), *docs, n_terms, doc_ids=ids)
+    sample = np.arange(0, nq, 25)
+    with m.SparseIndex(path, device=0) as ix:
+        dix = DenseIndex(p)
+        d_scores, d_idx = dix.search(q, depth)
+        r2o = row_to_ordinal(ix, ids)
+        ords, fs, cnt, ms = hybrid_search(ix, dix, qp, qt, qw, q, depth, k, alpha, r2o)
+        got_ids = {int(i): ix.docids(ords[i, :cnt[i]]) for i in sample}
+        dix.close()
+    assert ms["dense_gemm"] > 0 and ms["fusion"] > 0
+    # (a) dense top-1000 of the sampled queries
+    ws, wi = _dense_oracle(q[sample], p, depth)
+    assert np.abs(d_scores[sample] - ws).max() <= 1e-5
+    diff = d_idx[sample] != wi
+    if diff.any():  # rows may swap only where two scores are closer than the f32 accumulation noise
+        s_all = q[sample].astype(np.float16).astype(np.float32) @ p.astype(np.float16).astype(np.float32).T
+        gap = np.abs(ws - np.take_along_axis(s_all, d_idx[sample], axis=1))
+        assert gap[diff].max() <= 2e-6 and diff.mean() < 0.01
+    assert (np.diff(d_scores, axis=1) <= 0).all() and (d_idx >= 0).all()
+    # (b) the oracle pipeline on the sampled queries
+    oix, order = helpers.taat_oracle(docs, n_terms, ids)
+    sorted_ids = [ids[r] for r in order]
+    sel = np.concatenate([np.arange(qp[i], qp[i + 1]) for i in sample])
+    sp = np.concatenate([[0], np.cumsum(qp[sample + 1] - qp[sample])]).astype(np.int64)
+    wo, wsc, wn = oix.search(sp, qt[sel], qw[sel], depth, threads=16)
+    qids = [str(int(i)) for i in sample]
+    o_sparse = oracle.get_run_dict(qids, [[float(np.float32(x)) for x in wsc[j, :wn[j]]] for j in range(len(sample))],
+                                   [[sorted_ids[int(d)] for d in wo[j, :wn[j]]] for j in range(len(sample))], False)
+    o_dense = oracle.get_run_dict(qids, ws, np.array([[ids[j] for j in row] for row in wi]), False)
+    want = oracle.fuse([o_dense, o_sparse], [alpha, 1 - alpha])
+    worst = 0.0
+    for j, i in enumerate(sample):
+        qid = qids[j]
+        ranked = sorted(want[qid].items(), key=lambda kv: (-float(kv[1]), kv[0].encode()))[:k]
+        assert cnt[i] == len(ranked) == k
+        for r, (doc, score) in enumerate(ranked):
+            worst = max(worst, abs(float(fs[i, r]) - float(score)))
+            g = got_ids[int(i)][r]
+            if g != doc:  # only a near-tie in the fused score may swap neighbours
+                assert g in want[qid] and abs(float(want[qid][g]) - float(score)) <= 2e-6, (qid, r, g, doc)
+    assert worst <= 1e-5
 
 
 def test_randomised_configurations(m, tmp_path):
