@@ -1,26 +1,43 @@
 #!/usr/bin/env python3
 """Benchmark of the sparse-search hot path on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run, one rank per GPU)
+    python bench.py --gpus N --steps K --warmup W
 
-A "step" is one pass of the hot path over one batch of synthetic queries: the scoring kernel + top-k merge for every
+N > 1 without a launcher: this process starts `python -m torch.distributed.run --nproc-per-node N bench.py ...` as a
+child BEFORE anything touches the GPU, relays rank 0's JSON line and exits with the child's status (the reference's
+launcher line is `deepspeed --num_gpus=4 src/search.py ...`, scripts/search_sparse.sh:14). Under a launcher
+(WORLD_SIZE set) it is one rank of N, one GPU per rank.
+
+A "step" is one pass of the hot path over one batch of synthetic queries: the scoring kernels + top-k merge for every
 query of the batch, with the index and the CSR queries already resident in HBM.
 
 Headline workload (BASELINE.json metric, configs[1]): Flickr30K-shape text->image sparse search, top-10.
   N > 1: the reference's own data parallelism (src/search.py:180-182): every rank holds the (16 MB) index and scores
   its own queries; no data-path collective; "scaling": "weak".
-Extra object "c4_1m" (BASELINE.json configs[3], the north-star target): 1 M docs / 10 000 queries; at N > 1 the index
-  is doc-range sharded over the ranks and the per-shard top-k lists are merged after ONE RCCL all-gather (exact);
-  "scaling": "strong".
+Extra objects (never part of `value`):
+  "c3_coco5k"  configs[2]: COCO-5K shapes, both directions, 1 GPU.
+  "c4_1m"      configs[3], the north-star target: 1 M docs / 10 000 queries; at N > 1 the index is doc-range sharded over
+               the ranks and the per-shard top-k lists are merged after ONE RCCL all-gather (exact), "scaling": "strong";
+               plus the literal term-range partition (every rank resident with its own term range only).
+  "c5_hybrid"  configs[4]: dense fp16 MFMA + sparse + min-max fusion, 1 GPU.
 
-rank 0 prints ONE JSON line. torch is used only as launcher plumbing (gloo barrier / max-reduce); the search path is
-ctypes -> libmsr.so -> HIP.
+Failure policy: a rank that cannot get its own GPU, an RCCL communicator that does not come up (unless
+--allow-gloo-fallback), or an exchange that does not finish within --c4-timeout end the run with a NON-ZERO status;
+the JSON line is still printed, with "error" / "hung" fields saying what happened.
+
+rank 0 prints ONE JSON line. torch is launcher plumbing only (gloo barrier / max-reduce, the contract's
+torch.cuda.synchronize); the search path is ctypes -> libmsr.so -> HIP. libmsr.so is loaded BEFORE torch so that the
+process resolves ONE HIP runtime and ONE librccl — the /opt/rocm ones libmsr.so was compiled against (torch ships
+older copies under torch/lib with the same sonames; whichever is loaded first serves both).
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import re
+import socket
+import subprocess
 import sys
 import tempfile
 import time
@@ -30,29 +47,128 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6.3 TB/s is what a copy achieves
+# ceilings from MI355X_MICROARCH.md
+HBM_PEAK_GBS = 8000.0    # HBM3E spec peak; ~6.3 TB/s is what a copy achieves
+L2_PEAK_GBS = 34500.0    # aggregate L2 -> CU bandwidth (8 XCDs)
+MFMA_F16_PEAK_TF = 2500.0  # dense fp16/bf16 MFMA peak
+N_SIMDS = 1024           # 256 CUs x 4 SIMDs
+N_XCDS = 8
+COUNTERS_FILE = os.path.join(ROOT, "profiles", "r02_counters.json")
+
+EXIT_LAUNCH = 2   # bad launch: fewer GPUs than ranks, WORLD_SIZE / --gpus mismatch
+EXIT_HUNG = 3     # the multi-rank exchange did not finish (watchdog)
+EXIT_COMM = 4     # RCCL communicator did not come up / exchange failed
+
+_PHASE = "start"
 
 
 def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
+def phase(name, rank=None):
+    """Per-rank progress marker on stderr: when a run hangs, the last marker of every rank says where."""
+    global _PHASE
+    _PHASE = name
+    log(f"[bench r{os.environ.get('RANK', '0') if rank is None else rank}] phase: {name}")
+
+
+# ------------------------------------------------------------------------------------------------ launcher
+def parse_args(argv):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--flickr-images", type=int, default=31014)
+    ap.add_argument("--tile-docs", type=int, default=0)
+    ap.add_argument("--c4-docs", type=int, default=1_000_000)
+    ap.add_argument("--c4-queries", type=int, default=10_000)
+    ap.add_argument("--c4-tile-docs", type=int, default=0)
+    ap.add_argument("--dense-max", type=int, default=-1, help="index build option dense_max_terms (-1: library default)")
+    ap.add_argument("--dense-density", type=float, default=-1.0, help="index build option dense_min_density")
+    ap.add_argument("--c4-timeout", type=float, default=900.0, help="watchdog for the 1 M-doc object at N > 1 (s)")
+    ap.add_argument("--no-c3", action="store_true", help="skip the COCO-5K (config 3) extra object")
+    ap.add_argument("--only-c3", action="store_true", help="(profiling) run only the COCO-5K workloads")
+    ap.add_argument("--no-c4", action="store_true", help="skip the 1 M-doc extra object")
+    ap.add_argument("--no-term-shards", action="store_true", help="skip the term-range sharded variant at N > 1")
+    ap.add_argument("--only-c4", action="store_true", help="(profiling) run only the 1 M-doc workload")
+    ap.add_argument("--c5-docs", type=int, default=5000)
+    ap.add_argument("--c5-queries", type=int, default=25010)
+    ap.add_argument("--no-c5", action="store_true", help="skip the hybrid (config 5) extra object")
+    ap.add_argument("--only-c5", action="store_true", help="(profiling) run only the hybrid workload")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline / parity samples")
+    ap.add_argument("--cpu-seconds", type=float, default=8.0, help="CPU work per baseline row (s)")
+    ap.add_argument("--cpu-threads", type=int, default=min(16, os.cpu_count() or 1))
+    ap.add_argument("--host-threads", type=int, default=min(16, os.cpu_count() or 1))
+    ap.add_argument("--allow-gloo-fallback", action="store_true",
+                    help="if RCCL cannot be initialised, move the per-shard lists through gloo instead of failing")
+    ap.add_argument("--allow-oversubscribe", action="store_true",
+                    help="(rehearsal on a small box) let several ranks share one GPU instead of failing")
+    ap.add_argument("--launcher-selftest", action="store_true",
+                    help="ranks only rendezvous (gloo), barrier, max-reduce and print; no GPU work (CPU test of the launcher)")
+    return ap.parse_args(argv)
+
+
+def visible_gpus():
+    import torch  # device_count() does not initialise the GPU on this image
+
+    return int(torch.cuda.device_count())
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def launch_ranks(args, argv):
+    """--gpus N > 1 outside a launcher: start N ranks as a child process group and relay rank 0's line."""
+    if not args.launcher_selftest and not args.allow_oversubscribe:
+        n_dev = visible_gpus()
+        if n_dev < args.gpus:
+            log(f"[bench] ERROR: --gpus {args.gpus} but only {n_dev} HIP device(s) are visible; refusing to stack ranks on "
+                f"one GPU (a 1-GPU number must not be reported as n_gpus={args.gpus}). "
+                f"Use --allow-oversubscribe only for a plumbing rehearsal.")
+            return EXIT_LAUNCH
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + list(argv)
+    log("[bench] launching: " + " ".join(cmd))
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    p = subprocess.run(cmd, stdout=subprocess.PIPE, env=env)
+    lines = [ln for ln in p.stdout.decode("utf-8", "replace").splitlines() if ln.strip().startswith("{")]
+    if lines:
+        print(lines[-1], flush=True)
+    elif p.returncode == 0:
+        log("[bench] ERROR: the ranks exited 0 but printed no JSON line")
+        return 1
+    return p.returncode
+
+
 class Ranks:
     """Launcher plumbing: rank info, barrier and max-over-ranks (gloo; the data path never touches torch)."""
 
-    def __init__(self, n_gpus):
+    def __init__(self, args):
         self.world = int(os.environ.get("WORLD_SIZE", "1"))
         self.rank = int(os.environ.get("RANK", "0"))
         self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-        try:  # rehearsals with more ranks than GPUs (1-GPU box) wrap around; a real node has one GPU per rank
-            import torch
-
-            n_dev = torch.cuda.device_count()
-            if n_dev > 0:
-                self.local_rank %= n_dev
-        except Exception:
-            pass
         self.dist = None
+        if args.gpus != self.world:
+            log(f"[bench r{self.rank}] ERROR: --gpus {args.gpus} but WORLD_SIZE={self.world}: launch with "
+                f"--nproc-per-node {args.gpus} (or run `python bench.py --gpus {args.gpus}` and let it launch the ranks)")
+            sys.exit(EXIT_LAUNCH)
+        if not args.launcher_selftest:
+            n_dev = visible_gpus()
+            if self.local_rank >= n_dev:
+                if args.allow_oversubscribe and n_dev > 0:
+                    log(f"[bench r{self.rank}] REHEARSAL: local rank {self.local_rank} shares GPU {self.local_rank % n_dev}")
+                    self.local_rank %= n_dev
+                else:
+                    log(f"[bench r{self.rank}] ERROR: local rank {self.local_rank} has no GPU of its own "
+                        f"({n_dev} visible)")
+                    sys.exit(EXIT_LAUNCH)
         if self.world > 1:
             import datetime
 
@@ -61,8 +177,6 @@ class Ranks:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             dist.init_process_group("gloo", timeout=datetime.timedelta(minutes=20))
             self.dist = dist
-        if n_gpus != self.world:
-            log(f"[bench] note: --gpus {n_gpus} but WORLD_SIZE={self.world}; using WORLD_SIZE")
 
     def barrier(self):
         if self.dist:
@@ -76,6 +190,13 @@ class Ranks:
         t = torch.tensor([x], dtype=torch.float64)
         self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
         return float(t.item())
+
+    def gather_objects(self, obj):
+        if not self.dist:
+            return [obj]
+        out = [None] * self.world
+        self.dist.all_gather_object(out, obj)
+        return out
 
     def bcast_bytes(self, b, n):
         if not self.dist:
@@ -94,11 +215,13 @@ class Ranks:
 
 
 _SYNC_DEVICE = 0
+_M = None
 
 
 def device_sync():
-    """Contract: torch.cuda.synchronize() on both sides of the timed region (device-wide, covers libmsr's stream).
-    Always on THIS rank's GPU: a bare synchronize() would create a context on GPU 0 from every rank."""
+    """Contract: a device-wide fence on both sides of the timed region, on THIS rank's GPU: hipDeviceSynchronize
+    through libmsr.so (covers libmsr's own stream) and torch.cuda.synchronize() as the contract names it."""
+    _M.device_sync(_SYNC_DEVICE)
     try:
         import torch
 
@@ -119,7 +242,7 @@ def hbm_copy_gbs():
         try:
             import torch
 
-            dev = torch.device("cuda", _SYNC_DEVICE if isinstance(_SYNC_DEVICE, int) else 0)
+            dev = torch.device("cuda", _SYNC_DEVICE)
             n = 1 << 30
             a = torch.empty(n, dtype=torch.uint8, device=dev)
             b = torch.empty(n, dtype=torch.uint8, device=dev)
@@ -166,31 +289,114 @@ def timed_steps(batch, k, steps, warmup, ranks, sharded=False, step=None):
     return ranks.max(dt), score_ms / max(calls, 1), merge_ms / max(calls, 1)
 
 
-def roofline(batch, k, score_ms_avg, workload_name):
-    by, postings = batch.algo_bytes(k)
-    achieved = by / (score_ms_avg * 1e-3) / 1e9 if score_ms_avg > 0 else 0.0
-    traffic = None
-    tf = os.path.join(ROOT, "profiles", "traffic.json")  # HBM bytes per launch from rocprofv3 --pmc runs
-    if os.path.exists(tf):
+# ------------------------------------------------------------------------------------------------ roofline
+_COUNTERS = None
+
+
+def counters(workload, kernel_re):
+    """Per-STEP counter sums of the kernels matching `kernel_re` in one profiled workload, from the committed
+    rocprofv3 --pmc passes (profiles/r02_counters.json, written by scripts/prof_counters.py; one pass per counter
+    group, as MI355X_MICROARCH.md prescribes). None when the workload was not profiled."""
+    global _COUNTERS
+    if _COUNTERS is None:
         try:
-            traffic = json.load(open(tf)).get(workload_name)
+            _COUNTERS = json.load(open(COUNTERS_FILE))
         except Exception:
-            traffic = None
-    # One step = the staged search's two score_tiles launches (first 1/16 of the tiles, then the rest with the
-    # thresholds those gave): bytes, traffic and kernel_ms are all per step, i.e. summed over both.
-    return {"bound": "hbm", "kernel": "score_tiles", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
-            "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-            "algorithmic_bytes_per_launch": by, "postings_per_launch": postings,
-            "hbm_copy_measured": hbm_copy_gbs(), "kernel_ms": round(score_ms_avg, 4), "launches_per_step": 2 if batch.index.n_tiles >= 2 else 1,
-            "note": "achieved = SURVEY §8d algorithmic bytes / kernel time; it can exceed the HBM peak because a tile's "
-                    "postings are re-read by every query from the XCDs' L2, not from HBM (traffic = measured HBM-side "
-                    "bytes per step); the kernel's own limiters are VALU issue (64-74 % busy) and L2->CU bandwidth "
-                    "(DESIGN.md §7)"}
+            _COUNTERS = {}
+    w = _COUNTERS.get(workload)
+    if not w:
+        return None
+    tot = {}
+    for name, c in w.get("kernels", {}).items():
+        if re.search(kernel_re, name):
+            for key, v in c.items():
+                tot[key] = tot.get(key, 0.0) + float(v)
+    if not tot:
+        return None
+    steps = float(w.get("steps", 1))
+    return {key: v / steps for key, v in tot.items()}
 
 
-def cpu_baseline(wl, got, target_seconds, threads):
+def binding_fractions(c, kernel_ms):
+    """The ceilings a kernel can actually run into, as fractions <= 1, from per-step counters `c` and the LIVE kernel
+    time per step: HBM-side traffic vs 8 TB/s, L2 hits x 128 B vs 34.5 TB/s, VALU issue (quad-cycle busy count vs the
+    SIMD-cycles of the profiled dispatches), plus scalar instructions per vector instruction."""
+    out = {}
+    t = kernel_ms * 1e-3
+    if c is None or t <= 0:
+        return out
+    if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
+        # KiB units; FETCH_SIZE counts 64 B per 128-B request on gfx950 -> x2 (MI355X_MICROARCH.md, HBM section)
+        traffic = (2.0 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0
+        out["traffic"] = int(traffic)
+        out["hbm_frac"] = round(traffic / t / (HBM_PEAK_GBS * 1e9), 4)
+    if "TCC_HIT_sum" in c:
+        out["l2_hit_bytes"] = int(c["TCC_HIT_sum"] * 128)
+        out["l2_frac"] = round(c["TCC_HIT_sum"] * 128.0 / t / (L2_PEAK_GBS * 1e9), 4)
+        if "TCC_MISS_sum" in c:
+            out["l2_hit_rate"] = round(c["TCC_HIT_sum"] / max(c["TCC_HIT_sum"] + c["TCC_MISS_sum"], 1.0), 4)
+    if "SQ_ACTIVE_INST_VALU" in c and "GRBM_GUI_ACTIVE" in c:
+        cycles = c["GRBM_GUI_ACTIVE"] / N_XCDS  # GRBM_GUI_ACTIVE is summed over the 8 XCDs
+        out["valu_busy"] = round(4.0 * c["SQ_ACTIVE_INST_VALU"] / max(cycles * N_SIMDS, 1.0), 4)
+        if "SQ_ACTIVE_INST_LDS" in c:
+            out["lds_issue_busy"] = round(4.0 * c["SQ_ACTIVE_INST_LDS"] / max(cycles * N_SIMDS, 1.0), 4)
+    if "SQ_INSTS_SALU" in c and "SQ_INSTS_VALU" in c:
+        out["salu_per_valu"] = round(c["SQ_INSTS_SALU"] / max(c["SQ_INSTS_VALU"], 1.0), 3)
+    return out
+
+
+def sparse_roofline(batch, k, score_ms_avg, workload_name, kernel_re="score_tiles"):
+    """roofline object of the sparse scorer: the binding ceiling is whichever of {HBM traffic, L2 -> CU bytes, VALU
+    issue} the counters put highest; SURVEY §8d's algorithmic-bytes figure is kept beside it, labelled for what it is."""
+    by, postings = batch.algo_bytes(k)
+    algo_gbs = by / (score_ms_avg * 1e-3) / 1e9 if score_ms_avg > 0 else 0.0
+    fr = binding_fractions(counters(workload_name, kernel_re), score_ms_avg)
+    cands = {"hbm": fr.get("hbm_frac"), "l2": fr.get("l2_frac"), "valu": fr.get("valu_busy")}
+    cands = {b: v for b, v in cands.items() if v is not None}
+    r = {"kernel": "score_tiles", "kernel_ms": round(score_ms_avg, 4),
+         "launches_per_step": 2 if batch.index.n_tiles >= 2 else 1}
+    if cands:
+        bound = max(cands, key=cands.get)
+        r["bound"] = bound
+        r["frac"] = cands[bound]
+        if bound == "hbm":
+            r.update(achieved=round(fr["traffic"] / (score_ms_avg * 1e-3) / 1e9, 1), peak=HBM_PEAK_GBS, unit="GB/s")
+        elif bound == "l2":
+            r.update(achieved=round(fr["l2_hit_bytes"] / (score_ms_avg * 1e-3) / 1e9, 1), peak=L2_PEAK_GBS, unit="GB/s")
+        else:
+            r.update(achieved=round(100.0 * fr["valu_busy"], 2), peak=100.0, unit="% of VALU issue cycles")
+    else:
+        r.update(bound="hbm", frac=None, achieved=None, peak=HBM_PEAK_GBS, unit="GB/s")
+    r.update({key: fr.get(key) for key in ("hbm_frac", "l2_frac", "valu_busy", "salu_per_valu", "lds_issue_busy",
+                                            "l2_hit_rate")})
+    r["traffic"] = fr.get("traffic")
+    r["algorithmic"] = {"bytes_per_step": by, "postings_per_step": postings, "gbps": round(algo_gbs, 1),
+                        "over_hbm_peak": round(algo_gbs / HBM_PEAK_GBS, 4),
+                        "note": "SURVEY §8d bytes (6 B per posting, every query streams privately) / kernel time: NOT a "
+                                "ceiling for a query-batched scorer — a tile's postings are shared by the queries in "
+                                "flight through L2, stored as 4-byte postings / 2-byte dense-head weights"}
+    r["hbm_copy_measured"] = hbm_copy_gbs()
+    r["counters_source"] = "profiles/r02_counters.json (rocprofv3 --pmc, separate passes; scripts/prof_counters.py)"
+    return r
+
+
+# ------------------------------------------------------------------------------------------------ CPU baseline
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(wl, got, target_seconds, threads, rows=True):
     """The oracle's C restatement (multithreaded term-at-a-time) timed on this host on a bounded query sample, and
-    used as the checker of the GPU results on that sample. Checker only: nothing here feeds the GPU path."""
+    used as the checker of the GPU results on that sample. Checker only: nothing here feeds the GPU path.
+    Rows: 16 threads on one big batch (the reference's --threads 16, scripts/search_sparse.sh:17) is
+    the headline `value`; beside it every CPU this job may use, and the reference's own call shape of 4 queries per
+    batch_search call (scripts/search_sparse.sh:16)."""
     from oracle import taat
 
     dp, dt, dw = wl.docs
@@ -201,13 +407,21 @@ def cpu_baseline(wl, got, target_seconds, threads):
     build_s = time.perf_counter() - t0
 
     def sub(a, b):
-        return (qp[a : b + 1] - qp[a]), qt[qp[a] : qp[b]], qw[qp[a] : qp[b]]
+        return (qp[a: b + 1] - qp[a]), qt[qp[a]: qp[b]], qw[qp[a]: qp[b]]
 
-    probe = min(nq, max(4 * threads, 64))
-    t0 = time.perf_counter()
-    oix.search(*sub(0, probe), wl.k, threads=threads)
-    per_q = (time.perf_counter() - t0) / probe
-    n = int(min(nq, max(probe, target_seconds / max(per_q, 1e-9))))
+    def sized(thr, per_call=None):
+        """queries that fill ~target_seconds at this setting (from a short probe)"""
+        probe = min(nq, max(4 * thr, 64))
+        t1 = time.perf_counter()
+        if per_call:
+            for a in range(0, probe, per_call):
+                oix.search(*sub(a, min(a + per_call, probe)), wl.k, threads=thr)
+        else:
+            oix.search(*sub(0, probe), wl.k, threads=thr)
+        per_q = (time.perf_counter() - t1) / probe
+        return int(min(nq, max(probe, target_seconds / max(per_q, 1e-9))))
+
+    n = sized(threads)
     t0 = time.perf_counter()
     w_ord, w_sc, w_n = oix.search(*sub(0, n), wl.k, threads=threads)
     dt_s = time.perf_counter() - t0
@@ -215,23 +429,35 @@ def cpu_baseline(wl, got, target_seconds, threads):
     mask = np.arange(wl.k)[None, :] < w_n[:, None]
     mism = int((g_n[:n] != w_n).sum() + (g_ord[:n].astype(np.int64)[mask] != w_ord[mask]).sum()
                + (g_u32[:n].astype(np.int64)[mask] != w_sc[mask]).sum())
-    cpu_model = "unknown"
-    try:
-        for line in open("/proc/cpuinfo"):
-            if line.startswith("model name"):
-                cpu_model = line.split(":", 1)[1].strip()
-                break
-    except OSError:
-        pass
-    # (one thread count only: the 1-GPU box grants this job 16 CPUs, which is also the reference's setting,
-    # scripts/search_sparse.sh:17 — 128 threads on the same share measured SLOWER, 202 K vs 231 K q/s)
-    return {"value": round(n / dt_s, 1), "unit": "queries/s", "cores": threads, "kind": "port",
-            "cpu_model": cpu_model, "host_logical_cpus": os.cpu_count(),
-            "sample": f"first {n} of {nq} queries of the same workload, {threads} threads, exhaustive term-at-a-time "
-                      f"C restatement (oracle/oracle_taat.c); index build {build_s:.1f}s not timed",
-            "seconds": round(dt_s, 2)}, {"checked_queries": n, "mismatches": mism}
+    affinity = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    cb = {"value": round(n / dt_s, 1), "unit": "queries/s", "cores": threads, "kind": "port",
+          "cpu_model": cpu_model(), "host_logical_cpus": os.cpu_count(), "affinity_cpus": affinity,
+          "sample": f"first {n} of {nq} queries of the same workload, {threads} threads, one call, exhaustive "
+                    f"term-at-a-time C restatement (oracle/oracle_taat.c); index build {build_s:.1f}s not timed",
+          "seconds": round(dt_s, 2)}
+    if rows:
+        extra = []
+        thr_all = max(1, min(affinity, 256))
+        if thr_all != threads:
+            n2 = sized(thr_all)
+            t0 = time.perf_counter()
+            oix.search(*sub(0, n2), wl.k, threads=thr_all)
+            d2 = time.perf_counter() - t0
+            extra.append({"value": round(n2 / d2, 1), "cores": thr_all, "queries": n2, "seconds": round(d2, 2),
+                          "shape": f"one call, {thr_all} threads = every CPU this job may run on (sched_getaffinity)"})
+        n3 = sized(threads, per_call=4) // 4 * 4
+        t0 = time.perf_counter()
+        for a in range(0, n3, 4):
+            oix.search(*sub(a, a + 4), wl.k, threads=threads)
+        d3 = time.perf_counter() - t0
+        extra.append({"value": round(n3 / max(d3, 1e-9), 1), "cores": threads, "queries": n3, "seconds": round(d3, 2),
+                      "shape": f"4 queries per call, {threads} threads (the reference's per_device_batch_size 4 / "
+                               f"--threads 16, scripts/search_sparse.sh:16-17)"})
+        cb["rows"] = extra
+    return cb, {"checked_queries": n, "mismatches": mism}
 
 
+# ------------------------------------------------------------------------------------------------ workloads
 def run_headline(args, ranks, m, wlmod):
     seed = 1
     t0 = time.perf_counter()
@@ -247,6 +473,7 @@ def run_headline(args, ranks, m, wlmod):
     qp, qt, qw = wl.queries
     nq = len(qp) - 1
     batch = ix.batch(qp, qt, qw, wl.k)
+    phase("headline timed region")
     wall, score_ms, merge_ms = timed_steps(batch, wl.k, args.steps, args.warmup, ranks)
     out = {
         "metric": "queries/sec, Flickr30K-shape text->image sparse search (top-10), MI355X",
@@ -262,9 +489,15 @@ def run_headline(args, ranks, m, wlmod):
         "config": {"workload": wl.description, "queries_per_step_per_gpu": nq, "k": wl.k,
                    "tile_docs": ix.tile_docs, "n_tiles": ix.n_tiles,
                    "parallelism": "1 GPU" if ranks.world == 1 else f"dp{ranks.world} over queries, index replicated"},
+        "parity_status": "partial: bit-exact against this repo's CPU restatement (oracle/), which restates a DECLARED "
+                         "contract of pyserini/Lucene impact search; the reference holds no fixtures and Lucene cannot "
+                         "run here, so the scorer's parity is unpinned (DESIGN.md §3)",
+        "runtime": m.runtime_info(),
     }
+    devices = ranks.gather_objects({"rank": ranks.rank, "device": ix.device})
     if ranks.rank == 0:
-        out["roofline"] = roofline(batch, wl.k, score_ms, wl.name)
+        out["rank_devices"] = devices
+        out["roofline"] = sparse_roofline(batch, wl.k, score_ms, wl.name)
         out["roofline"]["merge_kernel_ms"] = round(merge_ms, 4)
         got = batch.fetch()
         # Recall@1/5/10 of the GPU results (qrels: caption j <-> image j // 5)
@@ -273,6 +506,7 @@ def run_headline(args, ranks, m, wlmod):
         target = (np.arange(nq) // 5)[:, None]
         out["recall"] = {f"R@{k}": round(float((ranked[:, :k] == target).any(axis=1).mean()), 5) for k in (1, 5, 10)}
         if ranks.world == 1 and not args.no_cpu:
+            phase("headline cpu baseline")
             cb, par = cpu_baseline(wl, got, args.cpu_seconds, args.cpu_threads)
             out["cpu_baseline"] = cb
             out["parity"] = par
@@ -317,8 +551,41 @@ def run_headline(args, ranks, m, wlmod):
     return out
 
 
-def run_c4(args, ranks, m, wlmod):
-    """configs[3]: 1 M docs; doc-range shards + one RCCL all-gather of the per-shard top-k (exact)."""
+def run_c3(args, ranks, m, wlmod):
+    """configs[2]: COCO-5K both directions, ~120-nnz queries, V = 30 000, top-10, one GPU."""
+    out = {}
+    for direction in ("i2t", "t2i"):
+        wl = wlmod.coco5k(direction, threads=args.host_threads)
+        tmp = tempfile.mkdtemp(prefix="msr_c3_")
+        path = m.build_index_from_csr(os.path.join(tmp, "c3.idx"), *wl.docs, wl.n_terms, threads=args.host_threads)
+        ix = m.SparseIndex(path, device=ranks.local_rank)
+        qp, qt, qw = wl.queries
+        nq = len(qp) - 1
+        batch = ix.batch(qp, qt, qw, wl.k)
+        phase(f"c3 {direction} timed region")
+        wall, score_ms, merge_ms = timed_steps(batch, wl.k, args.steps, args.warmup, ranks)
+        o = {"workload": wl.description + ", top-10", "value": round(nq * args.steps / wall, 1), "unit": "queries/s",
+             "ms_per_step": round(wall / args.steps * 1e3, 4), "n_tiles": ix.n_tiles, "tile_docs": ix.tile_docs,
+             "roofline": sparse_roofline(batch, wl.k, score_ms, wl.name)}
+        o["roofline"]["merge_kernel_ms"] = round(merge_ms, 4)
+        if not args.no_cpu:
+            cb, par = cpu_baseline(wl, batch.fetch(), min(args.cpu_seconds, 4.0), args.cpu_threads, rows=False)
+            o["cpu_baseline"] = cb
+            o["parity"] = par
+        out[direction] = o
+        batch.close()
+        ix.close()
+        try:
+            os.remove(path)
+            os.rmdir(tmp)
+        except OSError:
+            pass
+    return out
+
+
+def run_c4(args, ranks, m, wlmod, status):
+    """configs[3]: 1 M docs; doc-range shards + one RCCL all-gather of the per-shard top-k (exact); then the literal
+    term-range partition (every rank resident with its own term range only; exchange = reduce-scatter of accumulators)."""
     t0 = time.perf_counter()
     shm = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else tempfile.gettempdir()
     path = os.path.join(shm, f"msr_c4_{os.environ.get('MASTER_PORT', 'p')}_{os.getuid()}.idx")
@@ -326,6 +593,7 @@ def run_c4(args, ranks, m, wlmod):
     err = None
     if ranks.rank == 0:
         try:
+            phase("c4 corpus + index build")
             wl = wlmod.c4_1m(n_docs=args.c4_docs, n_queries=args.c4_queries, threads=args.host_threads)
             m.build_index_from_csr(path, *wl.docs, wl.n_terms, threads=args.host_threads, tile_docs=args.c4_tile_docs)
             log(f"[bench] c4 corpus + index in {time.perf_counter() - t0:.1f}s -> {path}")
@@ -339,6 +607,7 @@ def run_c4(args, ranks, m, wlmod):
         try:
             qp, qt, qw = m.synth_vectors(args.c4_queries, 120, 30000, seed=4, threads=args.host_threads)
             qp, qt, qw = qp.astype(np.int64), qt.astype(np.int32), qw.astype(np.int32)
+            phase("c4 open doc-range shard")
             ix = m.SparseIndex(path, device=ranks.local_rank, shard=ranks.rank, n_shards=ranks.world)
         except Exception as e:
             err = e
@@ -347,19 +616,26 @@ def run_c4(args, ranks, m, wlmod):
         exchange = "one RCCL all-gather of per-shard top-k + exact merge"
         step = None
         fallback_result = {}
+        comm_facts = None
         if sharded:
+            phase("c4 RCCL communicator init (doc-range shards)")
             uid = ranks.bcast_bytes(m.comm_unique_id() if ranks.rank == 0 else None, 128)
             try:
                 ix.comm_init(ranks.world, ranks.rank, uid)
+                comm_facts = ix.comm_info()
             except Exception as e:
                 err = e
             if ranks.any_failed(err is not None):
-                # RCCL could not be brought up (this cannot be rehearsed on a 1-GPU box): keep the doc-range shards and
-                # move the per-shard lists through torch.distributed (gloo) instead, merged by msr_merge_lists
-                log(f"[bench r{ranks.rank}] RCCL init failed ({err}); falling back to a gloo all-gather of the lists")
+                msg = f"RCCL communicator init failed on some rank (this rank: {err})"
+                if not args.allow_gloo_fallback:
+                    status["exit"] = EXIT_COMM
+                    raise RuntimeError(msg + "; pass --allow-gloo-fallback to move the lists through gloo instead")
+                # explicit opt-in: keep the doc-range shards and move the per-shard lists through torch.distributed
+                # (gloo) instead, merged by msr_merge_lists
+                log(f"[bench r{ranks.rank}] {msg}; --allow-gloo-fallback: gloo all-gather of the lists")
                 from mllm_sparse_retrieval_amd import dist as mdist
 
-                exchange = f"FALLBACK: gloo all-gather of host lists + msr_merge_lists (RCCL init failed: {err})"
+                exchange = f"FALLBACK: gloo all-gather of host lists + msr_merge_lists ({msg})"
                 sharded = False  # batch.search without the in-library exchange
 
                 def step():
@@ -368,6 +644,7 @@ def run_c4(args, ranks, m, wlmod):
                     g = mdist.all_gather_lists(ranks.dist, o, su, cnt)
                     fallback_result["r"] = ix.merge_lists(g[0], g[1], g[2], 10)
         batch = ix.batch(qp, qt, qw, 10)
+        phase("c4 timed region (doc-range shards)" if ranks.world > 1 else "c4 timed region")
         wall, score_ms, merge_ms = timed_steps(batch, 10, args.steps, args.warmup, ranks, sharded=sharded, step=step)
         nq = len(qp) - 1
         out = {"workload": f"synthetic {args.c4_docs} docs x128 nnz ({ix.n_postings} postings), {nq} queries x120 nnz, "
@@ -375,12 +652,19 @@ def run_c4(args, ranks, m, wlmod):
                "value": round(nq * args.steps / wall, 1), "unit": "queries/s", "n_gpus": ranks.world,
                "ms_per_step": round(wall / args.steps * 1e3, 3), "scaling": "strong",
                "parallelism": "1 GPU" if ranks.world == 1 else
-               f"index doc-range sharded over {ranks.world} GPUs ({ix.shard_ntiles} of {ix.n_tiles} tiles on rank 0), "
-               + exchange}
+               f"index DOC-range sharded over {ranks.world} GPUs ({ix.shard_ntiles} of {ix.n_tiles} tiles on rank 0), "
+               + exchange + " — the scaling path; term-range shards (below) are exact but exchange-bound"}
+        resident = ranks.gather_objects(ix.resident_bytes)
+        facts = ranks.gather_objects(comm_facts)
         if ranks.rank == 0:
-            out["roofline"] = roofline(batch, 10, score_ms, "c4_1m" if ranks.world == 1 else f"c4_1m_shard{ranks.world}")
+            out["resident_index_bytes_per_rank"] = resident
+            if ranks.world > 1:
+                out["rccl_ranks"] = facts[0][0] if facts[0] else None
+                out["rccl_comm"] = [{"ranks": f[0], "rank": f[1], "device": f[2]} if f else None for f in facts]
+            out["roofline"] = sparse_roofline(batch, 10, score_ms, "c4_1m" if ranks.world == 1 else f"c4_1m_shard{ranks.world}")
             out["roofline"]["merge_and_exchange_ms"] = round(merge_ms, 4)
             if ranks.world == 1 and not args.no_cpu:
+                phase("c4 cpu baseline")
                 cb, par = cpu_baseline(wl, batch.fetch(), args.cpu_seconds, args.cpu_threads)
                 out["cpu_baseline"] = cb
                 out["parity"] = par
@@ -391,28 +675,41 @@ def run_c4(args, ranks, m, wlmod):
             ix.comm_destroy()
         ix.close()
         if sharded and not args.no_term_shards:
-            # the north star's literal partition: term-range shards. Exact, but the exchange is a reduce-scatter of
-            # u32 accumulators (nq x N x 4 B), so it is exchange-bound by construction.
+            # the north star's literal partition: term-range shards, each rank RESIDENT with its own term range only
+            # (msr_index_open_termshard). Exact, but the exchange is a reduce-scatter of u32 accumulators
+            # (nq x N x 4 B), so it is exchange-bound by construction.
             terr = None
+            ixf = tb = None
             try:
-                ixf = m.SparseIndex(path, device=ranks.local_rank)              # every doc tile, own term range
+                phase("c4 open term-range shard")
+                ixf = m.SparseIndex(path, device=ranks.local_rank, term_shard=(ranks.rank, ranks.world))
                 uid = ranks.bcast_bytes(m.comm_unique_id() if ranks.rank == 0 else None, 128)
+                phase("c4 RCCL communicator init (term-range shards)")
                 ixf.comm_init(ranks.world, ranks.rank, uid)
-                tb = ixf.batch(qp, qt, qw, 10, term_shard=(ranks.rank, ranks.world))
+                tb = ixf.batch(qp, qt, qw, 10)
             except Exception as e:
                 terr = e
             if ranks.any_failed(terr is not None):
+                status["exit"] = EXIT_COMM
                 out["term_range_shards"] = {"error": f"setup failed on some rank (this rank: {terr})"}
             else:
-                twall, _, _ = timed_steps(tb, 10, max(1, min(args.steps, 3)), 1, ranks, sharded="terms")
+                phase("c4 timed region (term-range shards)")
                 tsteps = max(1, min(args.steps, 3))
+                twall, _, _ = timed_steps(tb, 10, tsteps, 1, ranks, sharded="terms")
                 tres = tb.fetch()
                 same = all((x == y).all() for x, y in zip(tres, doc_sharded_result))
+                tres_bytes = ranks.gather_objects(ixf.resident_bytes)
                 out["term_range_shards"] = {
                     "value": round(nq * tsteps / twall, 1), "unit": "queries/s", "ms_per_step": round(twall / tsteps * 1e3, 2),
                     "steps": tsteps, "identical_to_doc_range_result": bool(same),
+                    "resident_index_bytes_per_rank": tres_bytes,
+                    "term_range_rank0": [ixf.term_lo, ixf.term_hi],
                     "exchange": "ncclReduceScatter(sum) of u32 accumulator tiles, then ncclAllGather of per-range top-k"}
+                if not same:
+                    status["exit"] = 1
+            if tb is not None:
                 tb.close()
+            if ixf is not None:
                 ixf.comm_destroy()
                 ixf.close()
     finally:
@@ -425,6 +722,48 @@ def run_c4(args, ranks, m, wlmod):
     return out
 
 
+def c5_parity_sample(m, docs, n_terms, qp, qt, qw, p, q, depth, k, alpha, got, every):
+    """GPU hybrid results of every `every`-th query against the ORACLE pipeline: C oracle sparse top-depth + numpy
+    dense top-depth on the fp16-rounded inputs -> oracle.get_run_dict -> oracle.fuse (pinned to src/hybrid.py:32-53)
+    -> top-k. Fused scores within 1e-5; ids equal except near-ties (2e-6)."""
+    from oracle import oracle, taat
+
+    ords, fs, cnt, docid_of = got
+    n, nq = p.shape[0], q.shape[0]
+    sample = np.arange(0, nq, every)
+    ids = [str(i) for i in range(n)]
+    oix, order = taat.TaatIndex.from_rows_by_docid(*docs, n_terms, ids)
+    sorted_ids = [ids[r] for r in order]
+    sel = np.concatenate([np.arange(qp[i], qp[i + 1]) for i in sample])
+    sp = np.concatenate([[0], np.cumsum(qp[sample + 1] - qp[sample])]).astype(np.int64)
+    wo, wsc, wn = oix.search(sp, qt[sel], qw[sel], depth, threads=16)
+    s = q[sample].astype(np.float16).astype(np.float32) @ p.astype(np.float16).astype(np.float32).T
+    didx = np.lexsort((np.broadcast_to(np.arange(n), s.shape), -s), axis=1)[:, :depth]
+    dsc = np.take_along_axis(s, didx, axis=1)
+    qids = [str(int(i)) for i in sample]
+    o_sparse = oracle.get_run_dict(qids, [[float(np.float32(x)) for x in wsc[j, :wn[j]]] for j in range(len(sample))],
+                                   [[sorted_ids[int(d)] for d in wo[j, :wn[j]]] for j in range(len(sample))], False)
+    o_dense = oracle.get_run_dict(qids, dsc, np.array([[ids[j] for j in row] for row in didx]), False)
+    want = oracle.fuse([o_dense, o_sparse], [alpha, 1 - alpha])
+    worst, id_mism, near_tie_swaps = 0.0, 0, 0
+    for j, i in enumerate(sample):
+        ranked = sorted(want[qids[j]].items(), key=lambda kv: (-float(kv[1]), kv[0].encode()))[:k]
+        if cnt[i] != len(ranked):
+            id_mism += 1
+            continue
+        for r, (doc, score) in enumerate(ranked):
+            worst = max(worst, abs(float(fs[i, r]) - float(score)))
+            g = docid_of(int(ords[i, r]))
+            if g != doc:
+                if g in want[qids[j]] and abs(float(want[qids[j]][g]) - float(score)) <= 2e-6:
+                    near_tie_swaps += 1
+                else:
+                    id_mism += 1
+    return {"checked_queries": int(len(sample)), "max_abs_score_diff": worst, "score_tolerance": 1e-5,
+            "id_mismatches": id_mism, "near_tie_swaps": near_tie_swaps,
+            "checker": "oracle pipeline: oracle_taat.c + numpy dense on fp16-rounded inputs + oracle.fuse"}
+
+
 def run_c5(args, ranks, m):
     """configs[4]: hybrid dense + sparse, COCO-5K t->i shape: N = 5 000 docs (128 nnz + 4096-d fp16 unit vectors),
     25 010 queries (120 nnz + 4096-d), depth 1000 -> fused top-10, alpha 0.5 (scripts/search.sh:25,32). One GPU."""
@@ -433,6 +772,7 @@ def run_c5(args, ranks, m):
     n, nq, h, depth, k, alpha, n_terms = args.c5_docs, args.c5_queries, 4096, 1000, 10, 0.5, 30000
     docs = m.synth_vectors(n, 128, n_terms, seed=4, threads=args.host_threads)
     qp, qt, qw = m.synth_vectors(nq, 120, n_terms, seed=5, threads=args.host_threads)
+    qp, qt, qw = qp.astype(np.int64), qt.astype(np.int32), qw.astype(np.int32)
     rng = np.random.default_rng(4)
     p = rng.standard_normal((n, h), dtype=np.float32)
     p /= np.linalg.norm(p, axis=1, keepdims=True)
@@ -443,18 +783,40 @@ def run_c5(args, ranks, m):
     ix = m.SparseIndex(path, device=ranks.local_rank)
     dix = DenseIndex(p, device=ranks.local_rank)
     r2o = row_to_ordinal(ix, [str(i) for i in range(n)])
+    phase("c5 hybrid search")
     hybrid_search(ix, dix, qp, qt, qw, q, depth, k, alpha, r2o)                      # warm-up
     t0 = time.perf_counter()
     ords, fs, cnt, ms = hybrid_search(ix, dix, qp, qt, qw, q, depth, k, alpha, r2o)
     wall = time.perf_counter() - t0
     kern = sum(ms.values())
+    flops = 2.0 * nq * n * h
     out = {"workload": f"hybrid: {n} docs x (128 nnz + {h}-d fp16), {nq} queries x (120 nnz + {h}-d), depth {depth} -> "
                        f"fused top-{k}, alpha {alpha}",
            "value": round(nq / (kern * 1e-3), 1), "unit": "queries/s (kernel time, inputs resident)",
            "host_inclusive_queries_per_s": round(nq / wall, 1),
            "kernel_ms": {k2: round(v, 3) for k2, v in ms.items()},
-           "dense_tflops": round(2.0 * nq * n * h / (ms["dense_gemm"] * 1e-3) / 1e12, 1) if ms["dense_gemm"] > 0 else None,
+           "dense_tflops": round(flops / (ms["dense_gemm"] * 1e-3) / 1e12, 1) if ms["dense_gemm"] > 0 else None,
            "dtype": "f16 in / f32 accumulate (dense), u32 (sparse), f32 (fusion)"}
+    # roofline per stage: the GEMM against the dense fp16 MFMA peak; selection / fusion against HBM with the bytes
+    # they have to move (counter-backed traffic where profiled)
+    rl = {}
+    if ms["dense_gemm"] > 0:
+        tf = flops / (ms["dense_gemm"] * 1e-3) / 1e12
+        rl["dense_gemm"] = {"bound": "mfma", "achieved": round(tf, 1), "peak": MFMA_F16_PEAK_TF, "unit": "TFLOP/s",
+                            "frac": round(tf / MFMA_F16_PEAK_TF, 4), "kernel_ms": round(ms["dense_gemm"], 4),
+                            **binding_fractions(counters("c5_hybrid", "dense_scores"), ms["dense_gemm"])}
+    for stage, kre in (("dense_select", "select_tiles|dense_select"), ("fusion", "fuse_tiles"), ("sparse", "score_tiles")):
+        if ms.get(stage, 0) > 0:
+            fr = binding_fractions(counters("c5_hybrid", kre), ms[stage])
+            cands = {b: fr.get(key) for b, key in (("hbm", "hbm_frac"), ("l2", "l2_frac"), ("valu", "valu_busy"))
+                     if fr.get(key) is not None}
+            bound = max(cands, key=cands.get) if cands else None
+            rl[stage] = {"bound": bound, "frac": cands.get(bound) if bound else None, "kernel_ms": round(ms[stage], 4), **fr}
+    out["roofline"] = rl
+    if not args.no_cpu:
+        phase("c5 parity sample vs the oracle pipeline")
+        out["parity"] = c5_parity_sample(m, docs, n_terms, qp, qt, qw, p, q, depth, k, alpha,
+                                         (ords, fs, cnt, ix.docid), every=50)
     dix.close()
     ix.close()
     try:
@@ -466,66 +828,73 @@ def run_c5(args, ranks, m):
 
 
 def main():
+    argv = sys.argv[1:]
+    args = parse_args(argv)
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # nothing has touched the GPU yet (torch.cuda.device_count() does not): start the ranks as children
+        sys.exit(launch_ranks(args, argv))
+
     # stdout carries exactly ONE JSON line: keep a private handle to it and point fd 1 at stderr, so that banners
     # printed by native libraries (RCCL prints its version block at communicator init) cannot pollute it
     real_stdout = os.fdopen(os.dup(1), "w")
     os.dup2(2, 1)
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--flickr-images", type=int, default=31014)
-    ap.add_argument("--tile-docs", type=int, default=0)
-    ap.add_argument("--c4-docs", type=int, default=1_000_000)
-    ap.add_argument("--c4-queries", type=int, default=10_000)
-    ap.add_argument("--c4-tile-docs", type=int, default=0)
-    ap.add_argument("--dense-max", type=int, default=-1, help="index build option dense_max_terms (-1: library default)")
-    ap.add_argument("--dense-density", type=float, default=-1.0, help="index build option dense_min_density")
-    ap.add_argument("--c4-timeout", type=float, default=900.0, help="watchdog for the 1 M-doc object at N > 1 (s)")
-    ap.add_argument("--no-c4", action="store_true", help="skip the 1 M-doc extra object")
-    ap.add_argument("--no-term-shards", action="store_true", help="skip the term-range sharded variant at N > 1")
-    ap.add_argument("--only-c4", action="store_true", help="(profiling) run only the 1 M-doc workload")
-    ap.add_argument("--c5-docs", type=int, default=5000)
-    ap.add_argument("--c5-queries", type=int, default=25010)
-    ap.add_argument("--no-c5", action="store_true", help="skip the hybrid (config 5) extra object")
-    ap.add_argument("--only-c5", action="store_true", help="(profiling) run only the hybrid workload")
-    ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline / parity sample")
-    ap.add_argument("--cpu-seconds", type=float, default=10.0)
-    ap.add_argument("--cpu-threads", type=int, default=min(16, os.cpu_count() or 1))
-    ap.add_argument("--host-threads", type=int, default=min(16, os.cpu_count() or 1))
-    args = ap.parse_args()
 
-    ranks = Ranks(args.gpus)
-    global _SYNC_DEVICE
-    _SYNC_DEVICE = ranks.local_rank
+    global _SYNC_DEVICE, _M
+    if args.launcher_selftest:
+        ranks = Ranks(args)
+        ranks.barrier()
+        top = ranks.max(float(ranks.rank))
+        if ranks.rank == 0:
+            print(json.dumps({"launcher_selftest": True, "n_gpus": ranks.world, "max_rank_seen": int(top)}),
+                  file=real_stdout, flush=True)
+        ranks.close()
+        return
+
     import mllm_sparse_retrieval_amd as m  # raises if libmsr.so is missing: there is no fallback scorer
+    from mllm_sparse_retrieval_amd import _cabi
     from mllm_sparse_retrieval_amd import workloads as wlmod
+
+    _cabi.lib()   # libmsr.so (and with it /opt/rocm's HIP runtime + librccl) BEFORE torch, see the module docstring
+    _M = m
+    ranks = Ranks(args)
+    _SYNC_DEVICE = ranks.local_rank
 
     if args.dense_max >= 0:
         m.set_build_option("dense_max_terms", args.dense_max)
     if args.dense_density >= 0:
         m.set_build_option("dense_min_density", args.dense_density)
 
+    only = args.only_c3 or args.only_c4 or args.only_c5
     out = {}
-    if not args.only_c4 and not args.only_c5:
+    status = {"exit": 0}
+    if not only:
         out = run_headline(args, ranks, m, wlmod)
-    if ranks.world == 1 and not args.no_c5 and not args.only_c4:
+    if ranks.world == 1 and not args.no_c3 and (args.only_c3 or not only):
+        try:
+            out["c3_coco5k"] = run_c3(args, ranks, m, wlmod)
+        except Exception as e:
+            out["c3_coco5k"] = {"error": f"{type(e).__name__}: {e}"}
+            log(f"[bench] c3_coco5k failed: {out['c3_coco5k']['error']}")
+    if ranks.world == 1 and not args.no_c5 and (args.only_c5 or not only):
         try:
             out["c5_hybrid"] = run_c5(args, ranks, m)
         except Exception as e:
             out["c5_hybrid"] = {"error": f"{type(e).__name__}: {e}"}
             log(f"[bench] c5_hybrid failed: {out['c5_hybrid']['error']}")
     hung = False
-    if not args.no_c4 and not args.only_c5:
-        # The extra object must never take the headline line down: exceptions are caught, and at N > 1 (RCCL paths that
-        # cannot be rehearsed on a 1-GPU box) a watchdog bounds the wait so that the JSON line is printed regardless.
+    if not args.no_c4 and (args.only_c4 or not only):
+        # The extra object must never take the headline NUMBER down: exceptions are caught and recorded, and at N > 1 a
+        # watchdog bounds the wait so that the JSON line is printed regardless — but a failure or a hang there still
+        # ends the run with a non-zero status.
         box = {}
 
         def work():
             try:
-                box["c4"] = run_c4(args, ranks, m, wlmod)
+                box["c4"] = run_c4(args, ranks, m, wlmod, status)
             except Exception as e:
                 box["c4"] = {"error": f"{type(e).__name__}: {e}"}
+                if ranks.world > 1 and status["exit"] == 0:
+                    status["exit"] = 1
                 log(f"[bench r{ranks.rank}] c4_1m failed: {box['c4']['error']}")
 
         if ranks.world > 1:
@@ -536,16 +905,24 @@ def main():
             t.join(args.c4_timeout)
             if t.is_alive():
                 hung = True
-                box["c4"] = {"error": f"no completion within {args.c4_timeout:.0f}s (multi-rank exchange hung?)"}
+                box["c4"] = {"error": f"no completion within {args.c4_timeout:.0f}s; rank {ranks.rank} was in phase "
+                                      f"'{_PHASE}' (every rank logs its phases on stderr)", "hung_phase": _PHASE}
+                log(f"[bench r{ranks.rank}] WATCHDOG: stuck in phase '{_PHASE}'")
         else:
             work()
         out["c4_1m"] = box["c4"]
+    if hung:
+        out["hung"] = True
+    if status["exit"]:
+        out["exit_status"] = status["exit"]
     if ranks.rank == 0:
         print(json.dumps(out), file=real_stdout, flush=True)
     if hung:
         real_stdout.flush()
-        os._exit(0)  # a native call is stuck: leave without joining it
+        os._exit(EXIT_HUNG)  # a native call is stuck: leave without joining it, and say so with the status
     ranks.close()
+    if status["exit"]:
+        sys.exit(status["exit"])
 
 
 if __name__ == "__main__":

@@ -65,6 +65,9 @@ typedef struct msr_info {
     uint32_t shard_ntiles;  /* tiles resident on this handle */
     int32_t device;         /* HIP device ordinal, or -1 */
     uint32_t n_dense;       /* terms stored in the dense head */
+    uint32_t term_lo;       /* term-range shards: terms [term_lo, term_hi) are resident (else 0 .. n_terms) */
+    uint32_t term_hi;
+    uint64_t resident_bytes; /* bytes of the index (segment table + postings + dense head) this handle holds in HBM */
 } msr_info;
 
 /* ---- index build: replaces scripts/sparse_index.sh:12-18 (pyserini.index.lucene --impact --pretokenized) ----
@@ -92,6 +95,16 @@ int msr_index_open(const char* path, int device, msr_index** out);
  * postings is uploaded. Ordinals in results stay global. */
 int msr_index_open_shard(const char* path, int device, int shard, int n_shards, msr_index** out);
 
+/* Term-range shard `shard` of `n_shards` (the north star's partition, BASELINE.json configs[3]; no counterpart in the
+ * reference, which opens one whole index per rank, src/search.py:216,273): term ranges are contiguous in term id and
+ * balanced by postings; of every doc tile only the segments of the owned terms, the matching columns of the segment
+ * table and the dense-head pairs that hold an owned term are uploaded. Such a handle serves the term-range protocol only
+ * (msr_batch_create_termshard with the same shard / n_shards, msr_batch_search_termshard,
+ * msr_search_termshard_emulated_handles); a plain msr_batch_create on it is refused. */
+int msr_index_open_termshard(const char* path, int device, int shard, int n_shards, msr_index** out);
+
+/* Closing an index releases the device buffers of every batch still alive on it and detaches those batches: they
+ * fail with MSR_E_INVAL afterwards and msr_batch_destroy only frees the host object. */
 void msr_index_close(msr_index* ix);
 int msr_index_info(const msr_index* ix, msr_info* info);
 
@@ -147,6 +160,13 @@ int msr_comm_init(msr_index* ix, int n_ranks, int rank, const char id[MSR_COMM_I
 /* local search + all-gather + merge; afterwards msr_batch_fetch returns the GLOBAL top-k on every rank. */
 int msr_batch_search_sharded(msr_batch* b, int k);
 int msr_comm_destroy(msr_index* ix);
+/* What the communicator of `ix` reports about itself (ncclCommCount / ncclCommUserRank / ncclCommCuDevice). */
+int msr_comm_info(const msr_index* ix, int* n_ranks, int* rank, int* device);
+/* One line of text for logs and the benchmark record: HIP runtime version, RCCL version and the path of the librccl
+ * the process actually resolved (dladdr). */
+int msr_runtime_info(char* buf, int cap);
+/* hipDeviceSynchronize on `device` (the benchmark's device-wide fence, independent of any torch state). */
+int msr_device_sync(int device);
 
 /* Term-range shards (the north star's partition; exact protocol of DESIGN.md §6): the batch holds only the query terms
  * of term range `shard` of `n_shards` (ranges are contiguous in term id and balanced by postings). Search = dump the
@@ -159,6 +179,11 @@ int msr_batch_search_termshard(msr_batch* b, int k);
 int msr_search_termshard_emulated(msr_index* ix, const int64_t* q_ptr, const int32_t* q_term, const int32_t* q_w, int nq,
                                   int k, uint32_t flags, int n_shards, uint32_t* out_doc_ord, float* out_score,
                                   uint32_t* out_score_u32, int32_t* out_n);
+/* ... and with one handle per logical shard, shards[g] opened by msr_index_open_termshard(path, dev, g, n_shards) on
+ * the same device: every shard scores out of its own partial residency. */
+int msr_search_termshard_emulated_handles(msr_index* const* shards, int n_shards, const int64_t* q_ptr,
+                                          const int32_t* q_term, const int32_t* q_w, int nq, int k, uint32_t flags,
+                                          uint32_t* out_doc_ord, float* out_score, uint32_t* out_score_u32, int32_t* out_n);
 
 /* Merge `n_lists` per-shard result lists (each [nq][k] as written by msr_batch_fetch) on the device of `ix`
  * with the same tie rule; used by the host-side exchange (torch.distributed all_gather) and by tests. */

@@ -38,6 +38,7 @@ class MsrInfo(C.Structure):
         ("n_docs", C.c_uint64), ("n_postings", C.c_uint64), ("n_vecs", C.c_uint64),
         ("n_terms", C.c_uint32), ("tile_docs", C.c_uint32), ("n_tiles", C.c_uint32), ("max_weight", C.c_uint32),
         ("shard_tile0", C.c_uint32), ("shard_ntiles", C.c_uint32), ("device", C.c_int32), ("n_dense", C.c_uint32),
+        ("term_lo", C.c_uint32), ("term_hi", C.c_uint32), ("resident_bytes", C.c_uint64),
     ]
 
 
@@ -49,6 +50,7 @@ SYMBOLS = [
     ("msr_index_build_csr", _I, [_CP, _U64, _U32, _VP, _VP, _VP, _VP, _VP, _I, _U32]),
     ("msr_index_open", _I, [_CP, _I, C.POINTER(_VP)]),
     ("msr_index_open_shard", _I, [_CP, _I, _I, _I, C.POINTER(_VP)]),
+    ("msr_index_open_termshard", _I, [_CP, _I, _I, _I, C.POINTER(_VP)]),
     ("msr_index_close", None, [_VP]),
     ("msr_index_info", _I, [_VP, C.POINTER(MsrInfo)]),
     ("msr_term_lookup", _I, [_VP, _VP, _I, _VP]),
@@ -74,6 +76,10 @@ SYMBOLS = [
     ("msr_batch_create_termshard", _I, [_VP, _VP, _VP, _VP, _I, _I, _U32, _I, _I, C.POINTER(_VP)]),
     ("msr_batch_search_termshard", _I, [_VP, _I]),
     ("msr_search_termshard_emulated", _I, [_VP, _VP, _VP, _VP, _I, _I, _U32, _I, _VP, _VP, _VP, _VP]),
+    ("msr_search_termshard_emulated_handles", _I, [_VP, _I, _VP, _VP, _VP, _I, _I, _U32, _VP, _VP, _VP, _VP]),
+    ("msr_comm_info", _I, [_VP, C.POINTER(_I), C.POINTER(_I), C.POINTER(_I)]),
+    ("msr_runtime_info", _I, [_VP, _I]),
+    ("msr_device_sync", _I, [_I]),
     ("msr_merge_lists", _I, [_VP, _I, _I, _I, _VP, _VP, _VP, _VP, _VP, _VP, _VP]),
     ("msr_dense_open", _I, [_VP, _U64, _U32, _I, C.POINTER(_VP)]),
     ("msr_dense_search", _I, [_VP, _VP, _I, _I, _VP, _VP, _VP, C.POINTER(C.c_float), C.POINTER(C.c_float)]),

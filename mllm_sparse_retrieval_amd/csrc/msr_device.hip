@@ -6,6 +6,8 @@
 // (call site src/search.py:86-87; Lucene impact scoring):
 //     score(d) = sum over query terms t of  q_w(t) * tf(t, d),   top-k of the docs with score > 0,
 //     ties broken by external doc id ascending (= lower ordinal).
+#include <dlfcn.h>
+
 #include "msr_kernels.hpp"
 
 namespace msr {
@@ -123,6 +125,21 @@ int device_attach(msr_index* ix, int device) {
     }
     const uint64_t stride = (uint64_t)h->n_terms + 1;
     const uint32_t t0 = ix->shard_tile0, nt = ix->shard_ntiles;
+    const bool by_terms = ix->term_nshards > 0;
+    const uint32_t lo = by_terms ? ix->term_lo : 0u, hi = by_terms ? ix->term_hi : h->n_terms;
+    d->seg_terms = hi - lo;
+    d->term_base = lo;
+    // dense-head pairs this handle keeps: all of them, or (term shard) those holding at least one owned term
+    d->pair_local.assign(h->n_dense / 2, -1);
+    d->n_pairs = 0;
+    for (uint32_t p = 0; p < h->n_dense / 2; ++p) {
+        bool keep = !by_terms;
+        for (uint32_t s2 = 2 * p; s2 < 2 * p + 2 && !keep; ++s2) {
+            const uint32_t term = ix->host.dense_terms[s2];
+            keep = term != 0xFFFFFFFFu && term >= lo && term < hi;
+        }
+        if (keep) d->pair_local[p] = (int32_t)d->n_pairs++;
+    }
     if (nt) {
         const uint32_t* sp = ix->host.seg_ptr + (uint64_t)t0 * stride;
         // the kernels trust seg_ptr: a non-monotone or out-of-range table (corrupt file) must not reach the GPU
@@ -148,41 +165,104 @@ int device_attach(msr_index* ix, int device) {
                 }
             }
         }
-        d->vec_base = sp[0];
-        d->shard_vecs = (uint64_t)sp[(uint64_t)(nt - 1) * stride + h->n_terms] - d->vec_base;
-        const size_t seg_bytes = (size_t)nt * stride * 4;
-        // the kernel's unconditional loads may read the first 64 vecs of the shard even when it holds fewer
-        const size_t post_bytes = std::max<size_t>((size_t)d->shard_vecs * 16, 64 * 16);
-        if (hipMalloc(&d->d_seg_ptr, seg_bytes) != hipSuccess || hipMalloc(&d->d_postings, post_bytes) != hipSuccess) {
-            set_error("hipMalloc of %zu + %zu bytes for the index shard failed", seg_bytes, post_bytes);
-            return fail(MSR_E_NOMEM);
-        }
-        d->n_pairs = h->n_dense / 2;
-        const size_t dense_bytes = std::max<size_t>((size_t)nt * d->n_pairs * h->tile_docs * 4, 16);
+        const size_t dense_row = (size_t)h->tile_docs * 4;
+        const size_t dense_bytes = std::max<size_t>((size_t)nt * d->n_pairs * dense_row, 16);
         if (hipMalloc(&d->d_dense, dense_bytes) != hipSuccess) {
             set_error("hipMalloc of %zu bytes for the dense head failed", dense_bytes);
             return fail(MSR_E_NOMEM);
         }
-        if (d->n_pairs && hipMemcpy(d->d_dense, ix->host.dense + (uint64_t)t0 * d->n_pairs * h->tile_docs,
-                                    (size_t)nt * d->n_pairs * h->tile_docs * 4, hipMemcpyHostToDevice) != hipSuccess) {
-            set_error("upload of the dense head failed");
-            return fail(MSR_E_HIP);
+        const uint32_t np_all = h->n_dense / 2;
+        if (d->n_pairs == np_all) {
+            if (np_all && hipMemcpy(d->d_dense, ix->host.dense + (uint64_t)t0 * np_all * h->tile_docs,
+                                    (size_t)nt * np_all * dense_row, hipMemcpyHostToDevice) != hipSuccess) {
+                set_error("upload of the dense head failed");
+                return fail(MSR_E_HIP);
+            }
+        } else {
+            for (uint32_t t = 0; t < nt; ++t)
+                for (uint32_t p = 0; p < np_all; ++p) {
+                    if (d->pair_local[p] < 0) continue;
+                    if (hipMemcpy(reinterpret_cast<char*>(d->d_dense) + ((size_t)t * d->n_pairs + (size_t)d->pair_local[p]) * dense_row,
+                                  ix->host.dense + ((uint64_t)(t0 + t) * np_all + p) * h->tile_docs, dense_row,
+                                  hipMemcpyHostToDevice) != hipSuccess) {
+                        set_error("upload of the dense head failed");
+                        return fail(MSR_E_HIP);
+                    }
+                }
         }
-        if (hipMemcpy(d->d_seg_ptr, sp, seg_bytes, hipMemcpyHostToDevice) != hipSuccess ||
-            (d->shard_vecs && hipMemcpy(d->d_postings, ix->host.postings + (uint64_t)d->vec_base * 4,
-                                        (size_t)d->shard_vecs * 16, hipMemcpyHostToDevice) != hipSuccess)) {
-            set_error("upload of the index shard failed");
-            return fail(MSR_E_HIP);
+        if (!by_terms) {
+            d->vec_base = sp[0];
+            d->shard_vecs = (uint64_t)sp[(uint64_t)(nt - 1) * stride + h->n_terms] - d->vec_base;
+            const size_t seg_bytes = (size_t)nt * stride * 4;
+            // the kernel's unconditional loads may read the first 64 vecs of the shard even when it holds fewer
+            const size_t post_bytes = std::max<size_t>((size_t)d->shard_vecs * 16, 64 * 16);
+            if (hipMalloc(&d->d_seg_ptr, seg_bytes) != hipSuccess || hipMalloc(&d->d_postings, post_bytes) != hipSuccess) {
+                set_error("hipMalloc of %zu + %zu bytes for the index shard failed", seg_bytes, post_bytes);
+                return fail(MSR_E_NOMEM);
+            }
+            if (hipMemcpy(d->d_seg_ptr, sp, seg_bytes, hipMemcpyHostToDevice) != hipSuccess ||
+                (d->shard_vecs && hipMemcpy(d->d_postings, ix->host.postings + (uint64_t)d->vec_base * 4,
+                                            (size_t)d->shard_vecs * 16, hipMemcpyHostToDevice) != hipSuccess)) {
+                set_error("upload of the index shard failed");
+                return fail(MSR_E_HIP);
+            }
+            d->resident_bytes = seg_bytes + (size_t)d->shard_vecs * 16 + (size_t)nt * d->n_pairs * dense_row;
+        } else {
+            // Term-range shard: segments are term-ordered inside a tile, so the owned terms of tile t are ONE slice
+            // [sp[t][lo], sp[t][hi]) of its postings. The slices are packed back to back, and the segment table keeps
+            // only the owned columns, rebased to the packed positions: score_tiles runs unchanged on (term id - lo).
+            const uint64_t cols = (uint64_t)d->seg_terms + 1;
+            std::vector<uint32_t> seg((size_t)nt * cols);
+            uint64_t total = 0;
+            for (uint32_t t = 0; t < nt; ++t) {
+                const uint32_t* row = sp + (uint64_t)t * stride;
+                const uint32_t a = row[lo];
+                for (uint64_t j = 0; j < cols; ++j) seg[(size_t)t * cols + j] = (uint32_t)(total + (row[lo + j] - a));
+                total += (uint64_t)row[hi] - a;
+                if (total > 0xFFFFFFFFull) {
+                    set_error("term shard holds more than 2^32 posting vecs");
+                    return fail(MSR_E_RANGE);
+                }
+            }
+            d->vec_base = 0;
+            d->shard_vecs = total;
+            const size_t seg_bytes = seg.size() * 4, post_bytes = std::max<size_t>((size_t)total * 16, 64 * 16);
+            if (hipMalloc(&d->d_seg_ptr, seg_bytes) != hipSuccess || hipMalloc(&d->d_postings, post_bytes) != hipSuccess) {
+                set_error("hipMalloc of %zu + %zu bytes for the term shard failed", seg_bytes, post_bytes);
+                return fail(MSR_E_NOMEM);
+            }
+            bool ok = hipMemcpy(d->d_seg_ptr, seg.data(), seg_bytes, hipMemcpyHostToDevice) == hipSuccess;
+            for (uint32_t t = 0; t < nt && ok; ++t) {
+                const uint32_t* row = sp + (uint64_t)t * stride;
+                const uint64_t n = (uint64_t)row[hi] - row[lo];
+                if (n)
+                    ok = hipMemcpy(d->d_postings + (uint64_t)seg[(size_t)t * cols] * 4,
+                                   ix->host.postings + (uint64_t)row[lo] * 4, (size_t)n * 16, hipMemcpyHostToDevice) == hipSuccess;
+            }
+            if (!ok) {
+                set_error("upload of the term shard failed");
+                return fail(MSR_E_HIP);
+            }
+            d->resident_bytes = seg_bytes + (size_t)total * 16 + (size_t)nt * d->n_pairs * dense_row;
         }
     }
     return MSR_OK;
 }
+
+uint64_t device_resident_bytes(const msr_index* ix) { return ix->dev ? ix->dev->resident_bytes : 0; }
 
 void device_detach(msr_index* ix) {
     DeviceIndex* d = ix->dev;
     if (!d) return;
     (void)hipSetDevice(d->device);
     if (d->stream) (void)hipStreamSynchronize(d->stream);  // nothing may still read the staging buffer or the index
+    // batches that outlive the handle: their device buffers go now (into the pool that is purged below), the host
+    // objects stay with their owners and refuse further use
+    for (msr_batch* b : ix->live_batches) {
+        batch_release_device(b);
+        b->ix = nullptr;
+    }
+    ix->live_batches.clear();
     if (d->comm) ncclCommDestroy(d->comm);
     d->pool.purge();
     for (hipEvent_t e : d->spare_events) (void)hipEventDestroy(e);
@@ -241,50 +321,64 @@ using namespace msr;
 
 
 
-void batch_free(msr_batch* b) {
-    if (!b) return;
-    if (b->ix && b->ix->dev) (void)hipSetDevice(b->ix->dev->device);
+// Device buffers and events of a batch go back to the handle (pool, spare events). Needs the index alive: once the
+// index is closed the batch is detached (b->ix == nullptr) and holds nothing on the device any more.
+void batch_release_device(msr_batch* b) {
+    if (!b || !b->ix || !b->ix->dev) return;
+    DeviceIndex* d = b->ix->dev;
+    (void)hipSetDevice(d->device);
+    if (d->stream) (void)hipStreamSynchronize(d->stream);  // nothing in flight may still use the buffers
     // d_qptr .. d_n live inside pooled blocks; the rest are plain allocations
-    void* ptrs[] = {b->d_gather, b->d_stamps, b->d_S, b->d_R, b->d_tpart};
-    for (void* p : ptrs)
-        if (p) (void)hipFree(p);
-    DeviceIndex* d = (b->ix && b->ix->dev) ? b->ix->dev : nullptr;
-    if (d && d->stream && !b->pooled.empty()) (void)hipStreamSynchronize(d->stream);  // nothing in flight may still use them
-    for (auto& blk : b->pooled) {
-        if (d)
-            d->pool.release(blk.first, blk.second);
-        else
-            (void)hipFree(blk.first);
+    void** ptrs[] = {(void**)&b->d_gather, (void**)&b->d_stamps, (void**)&b->d_S, (void**)&b->d_R, (void**)&b->d_tpart};
+    for (void** p : ptrs) {
+        if (*p) (void)hipFree(*p);
+        *p = nullptr;
     }
+    for (auto& blk : b->pooled) d->pool.release(blk.first, blk.second);
+    b->pooled.clear();
+    b->d_qptr = b->d_qterm = b->d_qw = b->d_qdense = b->d_ord = b->d_su32 = nullptr;
+    b->d_sf32 = nullptr;
+    b->d_n = nullptr;
+    b->d_part = b->d_keys = nullptr;
     for (hipEvent_t e : b->events) {
         if (!e) continue;
-        if (d && d->spare_events.size() < 64)
+        if (d->spare_events.size() < 64)
             d->spare_events.push_back(e);
         else
             (void)hipEventDestroy(e);
     }
+    b->events.clear();
+    b->ev0 = b->ev1 = b->ev2 = nullptr;
+    b->calls = 0;
+    b->timed = false;
+    b->last_k = 0;
+}
+
+void batch_free(msr_batch* b) {
+    if (!b) return;
+    if (b->ix) {
+        batch_release_device(b);
+        auto& lb = b->ix->live_batches;
+        lb.erase(std::remove(lb.begin(), lb.end(), b), lb.end());
+    }
     delete b;
+}
+
+static int batch_alive(const msr_batch* b, const char* who) {
+    if (!b) {
+        set_error("%s: null batch", who);
+        return MSR_E_INVAL;
+    }
+    if (!b->ix || !b->ix->dev) {
+        set_error("%s: the batch's index has been closed", who);
+        return MSR_E_INVAL;
+    }
+    return MSR_OK;
 }
 
 extern "C" {
 
 }  // extern "C"
-
-// Term ownership for term-range sharding: G contiguous term-id ranges balanced by postings (cumulative df), the
-// same on every rank because it depends only on the index. bounds has G+1 entries.
-static void term_bounds(const msr::HostIndex& hx, int G, std::vector<uint32_t>& bounds) {
-    const uint32_t V = hx.h->n_terms;
-    uint64_t total = 0;
-    for (uint32_t v = 0; v < V; ++v) total += hx.df[v];
-    bounds.assign((size_t)G + 1, V);
-    bounds[0] = 0;
-    uint64_t acc = 0;
-    int g = 1;
-    for (uint32_t v = 0; v < V && g < G; ++v) {
-        acc += hx.df[v];
-        while (g < G && acc * (uint64_t)G >= total * (uint64_t)g) bounds[g++] = v + 1;
-    }
-}
 
 static int batch_create_impl(msr_index* ix, const int64_t* q_ptr, const int32_t* q_term, const int32_t* q_w, int nq,
                              int kmax, uint32_t flags, int shard, int n_shards, msr_batch** out) {
@@ -309,6 +403,11 @@ static int batch_create_impl(msr_index* ix, const int64_t* q_ptr, const int32_t*
     DeviceIndex* d = ix->dev;
     compute_df_shard(ix);
     uint32_t term_lo = 0, term_hi = h->n_terms;
+    if (ix->term_nshards > 0 && (n_shards != ix->term_nshards || shard != ix->term_shard)) {
+        set_error("this handle holds term shard %d of %d only: create its batches with msr_batch_create_termshard(..., %d, %d)",
+                  ix->term_shard, ix->term_nshards, ix->term_shard, ix->term_nshards);
+        return MSR_E_INVAL;
+    }
     if (n_shards > 0) {
         if (shard < 0 || shard >= n_shards) {
             set_error("bad term shard %d of %d", shard, n_shards);
@@ -332,7 +431,7 @@ static int batch_create_impl(msr_index* ix, const int64_t* q_ptr, const int32_t*
     }
     qterm.reserve((size_t)total_in);
     qw.reserve((size_t)total_in);
-    const uint32_t n_pairs = h->n_dense / 2;
+    const uint32_t n_pairs = d->n_pairs;  // resident pairs (a term shard keeps only the pairs with an owned term)
     std::vector<uint32_t> qdense((size_t)nq * n_pairs, 0u);  // packed 16-bit query weights of the dense-head terms
     std::vector<uint32_t> dsum(h->n_dense);
     uint64_t n_kept = 0;
@@ -370,14 +469,16 @@ static int batch_create_impl(msr_index* ix, const int64_t* q_ptr, const int32_t*
                 }
                 dsum[ds] += (uint32_t)w;
             } else {
-                qterm.push_back((uint32_t)t);
+                qterm.push_back((uint32_t)t - d->term_base);  // column of the (possibly term-sharded) segment table
                 qw.push_back((uint32_t)w);
             }
         }
         uint32_t pmask = 0;
         for (uint32_t s2 = 0; s2 < h->n_dense; ++s2) {
-            qdense[(size_t)i * n_pairs + (s2 >> 1)] |= dsum[s2] << (16 * (s2 & 1));
-            if (dsum[s2]) pmask |= 1u << (s2 >> 1);
+            if (!dsum[s2]) continue;
+            const int32_t lp = d->pair_local[s2 >> 1];  // >= 0: an owned term's pair is resident by construction
+            qdense[(size_t)i * n_pairs + (uint32_t)lp] |= dsum[s2] << (16 * (s2 & 1));
+            pmask |= 1u << lp;
         }
         if (bound > 0xFFFFFFFFull) {
             set_error("query %d: worst-case score %llu exceeds the exact u32 range", i, (unsigned long long)bound);
@@ -483,6 +584,7 @@ static int batch_create_impl(msr_index* ix, const int64_t* q_ptr, const int32_t*
             return fail(MSR_E_HIP);
         }
     }
+    ix->live_batches.push_back(b);
     *out = b;
     return MSR_OK;
 }
@@ -537,7 +639,7 @@ int batch_search_local(msr_batch* b, int k, bool final_arrays) {
     sa.part = b->d_part;
     sa.n_docs = h->n_docs;
     sa.vec_base = d->vec_base;
-    sa.n_terms = h->n_terms;
+    sa.n_terms = d->seg_terms;
     sa.tile0 = ix->shard_tile0;
     sa.nq = (uint32_t)b->nq;
     sa.q0 = 0;
@@ -616,8 +718,9 @@ int batch_search_local(msr_batch* b, int k, bool final_arrays) {
 }
 
 int msr_batch_search(msr_batch* b, int k) {
-    if (!b) {
-        set_error("msr_batch_search: null batch");
+    if (int rc = batch_alive(b, "msr_batch_search")) return rc;
+    if (b->ix->term_nshards > 0) {
+        set_error("msr_batch_search: this handle holds one term shard (partial sums only); use msr_batch_search_termshard");
         return MSR_E_INVAL;
     }
     if (k < 1 || k > b->kmax) {
@@ -628,17 +731,15 @@ int msr_batch_search(msr_batch* b, int k) {
 }
 
 int msr_batch_sync(msr_batch* b) {
-    if (!b) {
-        set_error("msr_batch_sync: null batch");
-        return MSR_E_INVAL;
-    }
+    if (int rc = batch_alive(b, "msr_batch_sync")) return rc;
     HIP_TRY(hipSetDevice(b->ix->dev->device));
     HIP_TRY(hipStreamSynchronize(b->ix->dev->stream));
     return MSR_OK;
 }
 
 int msr_batch_fetch(msr_batch* b, uint32_t* out_doc_ord, float* out_score, uint32_t* out_score_u32, int32_t* out_n) {
-    if (!b || b->last_k == 0) {
+    if (int rc0 = batch_alive(b, "msr_batch_fetch")) return rc0;
+    if (b->last_k == 0) {
         set_error("msr_batch_fetch: no search has run on this batch");
         return MSR_E_INVAL;
     }
@@ -671,7 +772,8 @@ int msr_batch_fetch(msr_batch* b, uint32_t* out_doc_ord, float* out_score, uint3
 }
 
 int msr_batch_kernel_ms(msr_batch* b, float* score_ms, float* merge_ms) {
-    if (!b || !b->timed) {
+    if (int rc0 = batch_alive(b, "msr_batch_kernel_ms")) return rc0;
+    if (!b->timed) {
         set_error("msr_batch_kernel_ms: no search has run on this batch");
         return MSR_E_INVAL;
     }
@@ -686,10 +788,6 @@ int msr_batch_kernel_ms(msr_batch* b, float* score_ms, float* merge_ms) {
 }
 
 int msr_batch_timing_reset(msr_batch* b) {
-    if (!b) {
-        set_error("msr_batch_timing_reset: null batch");
-        return MSR_E_INVAL;
-    }
     int rc = msr_batch_sync(b);
     if (rc != MSR_OK) return rc;
     b->calls = 0;
@@ -697,10 +795,6 @@ int msr_batch_timing_reset(msr_batch* b) {
 }
 
 int msr_batch_timing_sum(msr_batch* b, int* n_calls, float* score_ms, float* merge_ms) {
-    if (!b) {
-        set_error("msr_batch_timing_sum: null batch");
-        return MSR_E_INVAL;
-    }
     int rc = msr_batch_sync(b);
     if (rc != MSR_OK) return rc;
     double a = 0, c = 0;
@@ -723,7 +817,7 @@ int msr_batch_debug_stamps(msr_batch* b, unsigned long long out[8]) {
         return MSR_E_INVAL;
     }
     memset(out, 0, 8 * sizeof(unsigned long long));
-    if (!b->d_stamps) return MSR_OK;
+    if (!b->ix || !b->d_stamps) return MSR_OK;
     int rc = msr_batch_sync(b);
     if (rc != MSR_OK) return rc;
     HIP_TRY(hipMemcpy(out, b->d_stamps, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
@@ -927,10 +1021,7 @@ static int exchange_and_merge(msr_batch* b, int k) {
 }
 
 static int check_sharded_call(msr_batch* b, int k, const char* who) {
-    if (!b) {
-        set_error("%s: null batch", who);
-        return MSR_E_INVAL;
-    }
+    if (int rc = batch_alive(b, who)) return rc;
     if (k < 1 || k > b->kmax) {
         set_error("k=%d outside [1, kmax=%d]", k, b->kmax);
         return MSR_E_RANGE;
@@ -945,6 +1036,10 @@ static int check_sharded_call(msr_batch* b, int k, const char* who) {
 int msr_batch_search_sharded(msr_batch* b, int k) {
     int rc = check_sharded_call(b, k, "msr_batch_search_sharded");
     if (rc != MSR_OK) return rc;
+    if (b->ix->term_nshards > 0) {
+        set_error("msr_batch_search_sharded merges DOC-range shards; this handle is a term shard (msr_batch_search_termshard)");
+        return MSR_E_INVAL;
+    }
     HIP_TRY(hipSetDevice(b->ix->dev->device));
     rc = batch_search_local(b, k, false);  // per-shard exact top-k keys in d_keys ([nq][k])
     if (rc != MSR_OK) return rc;
@@ -1002,7 +1097,7 @@ static void fill_score_args(ScoreArgs& sa, msr_batch* b, int k) {
     sa.part = b->d_part;
     sa.n_docs = ix->host.h->n_docs;
     sa.vec_base = d->vec_base;
-    sa.n_terms = ix->host.h->n_terms;
+    sa.n_terms = d->seg_terms;
     sa.tile0 = ix->shard_tile0;
     sa.nq = (uint32_t)b->nq;
     sa.q0 = 0;
@@ -1025,7 +1120,7 @@ int msr_batch_search_termshard(msr_batch* b, int k) {
     DeviceIndex* d = ix->dev;
     const IndexHeader* h = ix->host.h;
     if (ix->shard_ntiles != h->n_tiles) {
-        set_error("term-sharded search needs a handle that holds every doc tile (open it with msr_index_open)");
+        set_error("term-sharded search needs a handle that holds every doc tile (msr_index_open or msr_index_open_termshard)");
         return MSR_E_INVAL;
     }
     if (b->term_nshards != d->n_ranks || b->term_shard != d->rank) {
@@ -1109,36 +1204,36 @@ int msr_batch_search_termshard(msr_batch* b, int k) {
 
 // The same protocol played on ONE GPU for `n_shards` logical term shards (tests, and a cross-check of the partition):
 // the shards' dumps are summed in place (dump_add) instead of by ncclReduceScatter; every logical rank then selects
-// its doc range and the n_shards lists are merged.
-int msr_search_termshard_emulated(msr_index* ix, const int64_t* q_ptr, const int32_t* q_term, const int32_t* q_w, int nq,
-                                  int k, uint32_t flags, int n_shards, uint32_t* out_doc_ord, float* out_score,
-                                  uint32_t* out_score_u32, int32_t* out_n) {
-    if (!ix || n_shards < 1 || n_shards > 64) {
-        set_error("msr_search_termshard_emulated: bad argument");
-        return MSR_E_INVAL;
-    }
-    if (!ix->dev) {
-        set_error("index handle has no HIP device bound; there is no CPU scoring path");
-        return MSR_E_NODEVICE;
-    }
-    if (ix->shard_ntiles != ix->host.h->n_tiles) {
-        set_error("term-sharded search needs a handle that holds every doc tile");
-        return MSR_E_INVAL;
-    }
+// its doc range and the n_shards lists are merged. hs[g] scores term shard g: either one handle that holds every term
+// (the same pointer n_shards times) or n_shards handles opened by msr_index_open_termshard on the same device.
+static int termshard_emulated_impl(msr_index* const* hs, int n_shards, const int64_t* q_ptr, const int32_t* q_term,
+                                   const int32_t* q_w, int nq, int k, uint32_t flags, uint32_t* out_doc_ord,
+                                   float* out_score, uint32_t* out_score_u32, int32_t* out_n) {
+    msr_index* ix = hs[0];
     DeviceIndex* d = ix->dev;
     const IndexHeader* h = ix->host.h;
     std::vector<msr_batch*> bs((size_t)n_shards, nullptr);
     uint32_t* d_S = nullptr;
     uint64_t *d_tpart = nullptr, *d_lists = nullptr;
     int rc = MSR_OK;
+    std::vector<uint64_t*> rank_part((size_t)n_shards, nullptr);
     auto cleanup = [&]() {
+        (void)hipStreamSynchronize(d->stream);
         for (msr_batch* x : bs) batch_free(x);
+        for (uint64_t* x : rank_part)
+            if (x) (void)hipFree(x);
         if (d_S) (void)hipFree(d_S);
         if (d_tpart) (void)hipFree(d_tpart);
         if (d_lists) (void)hipFree(d_lists);
     };
-    for (int g = 0; g < n_shards && rc == MSR_OK; ++g)
-        rc = batch_create_impl(ix, q_ptr, q_term, q_w, nq, k, flags, g, n_shards, &bs[g]);
+    for (int g = 0; g < n_shards && rc == MSR_OK; ++g) {
+        rc = batch_create_impl(hs[g], q_ptr, q_term, q_w, nq, k, flags, g, n_shards, &bs[g]);
+        // the batch's upload runs on ITS handle's stream; everything below runs on shard 0's stream
+        if (rc == MSR_OK && hs[g] != ix && hipStreamSynchronize(hs[g]->dev->stream) != hipSuccess) {
+            set_error("hipStreamSynchronize failed");
+            rc = MSR_E_HIP;
+        }
+    }
     if (rc != MSR_OK) {
         cleanup();
         return rc;
@@ -1155,7 +1250,6 @@ int msr_search_termshard_emulated(msr_index* ix, const int64_t* q_ptr, const int
     }
     // pass 1..: accumulators of every query tile, summed over the logical term shards; selection per logical rank
     // writes into that rank's slice of d_lists after a per-rank merge of its tpr tile lists.
-    std::vector<uint64_t*> rank_part((size_t)n_shards, nullptr);
     for (int r = 0; r < n_shards && rc == MSR_OK; ++r)
         if (hipMalloc(&rank_part[r], std::max<size_t>((size_t)p.tpr * per, 1) * 8) != hipSuccess) {
             set_error("hipMalloc failed in msr_search_termshard_emulated");
@@ -1181,7 +1275,6 @@ int msr_search_termshard_emulated(msr_index* ix, const int64_t* q_ptr, const int
         for (int r = 0; r < n_shards && rc == MSR_OK; ++r) {
             SelectArgs se;
             se.unsorted = 0;
-        se.unsorted = 0;
             se.src = d_S + (size_t)r * qn * p.range_elems;
             se.part = rank_part[r];
             se.n_docs = h->n_docs;
@@ -1228,11 +1321,94 @@ int msr_search_termshard_emulated(msr_index* ix, const int64_t* q_ptr, const int
             rc = msr_batch_fetch(b0, out_doc_ord, out_score, out_score_u32, out_n);
         }
     }
-    (void)hipStreamSynchronize(d->stream);
-    for (uint64_t* x : rank_part)
-        if (x) (void)hipFree(x);
     cleanup();
     return rc;
+}
+
+int msr_search_termshard_emulated(msr_index* ix, const int64_t* q_ptr, const int32_t* q_term, const int32_t* q_w, int nq,
+                                  int k, uint32_t flags, int n_shards, uint32_t* out_doc_ord, float* out_score,
+                                  uint32_t* out_score_u32, int32_t* out_n) {
+    if (!ix || n_shards < 1 || n_shards > 64) {
+        set_error("msr_search_termshard_emulated: bad argument");
+        return MSR_E_INVAL;
+    }
+    if (!ix->dev) {
+        set_error("index handle has no HIP device bound; there is no CPU scoring path");
+        return MSR_E_NODEVICE;
+    }
+    if (ix->shard_ntiles != ix->host.h->n_tiles || ix->term_nshards > 0) {
+        set_error("term-sharded search needs a handle that holds every doc tile and every term (or one handle per shard: "
+                  "msr_search_termshard_emulated_handles)");
+        return MSR_E_INVAL;
+    }
+    std::vector<msr_index*> hs((size_t)n_shards, ix);
+    return termshard_emulated_impl(hs.data(), n_shards, q_ptr, q_term, q_w, nq, k, flags, out_doc_ord, out_score,
+                                   out_score_u32, out_n);
+}
+
+int msr_search_termshard_emulated_handles(msr_index* const* shards, int n_shards, const int64_t* q_ptr,
+                                          const int32_t* q_term, const int32_t* q_w, int nq, int k, uint32_t flags,
+                                          uint32_t* out_doc_ord, float* out_score, uint32_t* out_score_u32, int32_t* out_n) {
+    if (!shards || n_shards < 1 || n_shards > 64) {
+        set_error("msr_search_termshard_emulated_handles: bad argument");
+        return MSR_E_INVAL;
+    }
+    for (int g = 0; g < n_shards; ++g) {
+        const msr_index* x = shards[g];
+        if (!x || !x->dev) {
+            set_error("shard handle %d is null or has no HIP device bound; there is no CPU scoring path", g);
+            return x ? MSR_E_NODEVICE : MSR_E_INVAL;
+        }
+        if (x->term_nshards != n_shards || x->term_shard != g || x->dev->device != shards[0]->dev->device ||
+            x->host.h->n_docs != shards[0]->host.h->n_docs || x->host.h->n_vecs != shards[0]->host.h->n_vecs) {
+            set_error("shard handle %d must be term shard %d of %d of the same index on the same device", g, g, n_shards);
+            return MSR_E_INVAL;
+        }
+    }
+    return termshard_emulated_impl(shards, n_shards, q_ptr, q_term, q_w, nq, k, flags, out_doc_ord, out_score,
+                                   out_score_u32, out_n);
+}
+
+// ------------------------------------------------------------------------------------------------ runtime facts
+int msr_comm_info(const msr_index* ix, int* n_ranks, int* rank, int* device) {
+    if (!ix || !ix->dev || !ix->dev->comm) {
+        set_error("msr_comm_info: no communicator on this handle (call msr_comm_init first)");
+        return MSR_E_COMM;
+    }
+    int c = 0, r = 0, dv = 0;
+    ncclResult_t e = ncclCommCount(ix->dev->comm, &c);
+    if (e == ncclSuccess) e = ncclCommUserRank(ix->dev->comm, &r);
+    if (e == ncclSuccess) e = ncclCommCuDevice(ix->dev->comm, &dv);
+    if (e != ncclSuccess) {
+        set_error("ncclCommCount / ncclCommUserRank failed: %s", ncclGetErrorString(e));
+        return MSR_E_COMM;
+    }
+    if (n_ranks) *n_ranks = c;
+    if (rank) *rank = r;
+    if (device) *device = dv;
+    return MSR_OK;
+}
+
+int msr_runtime_info(char* buf, int cap) {
+    if (!buf || cap < 1) {
+        set_error("msr_runtime_info: bad argument");
+        return MSR_E_INVAL;
+    }
+    int hip_rt = 0, rccl_v = 0;
+    (void)hipRuntimeGetVersion(&hip_rt);
+    (void)ncclGetVersion(&rccl_v);
+    Dl_info rccl_so, hip_so;
+    const char* rccl_path = dladdr(reinterpret_cast<void*>(&ncclGetVersion), &rccl_so) && rccl_so.dli_fname ? rccl_so.dli_fname : "?";
+    const char* hip_path = dladdr(reinterpret_cast<void*>(&hipRuntimeGetVersion), &hip_so) && hip_so.dli_fname ? hip_so.dli_fname : "?";
+    snprintf(buf, (size_t)cap, "hip_runtime=%d hip_lib=%s rccl=%d rccl_header=%d rccl_lib=%s", hip_rt, hip_path, rccl_v,
+             NCCL_VERSION_CODE, rccl_path);
+    return MSR_OK;
+}
+
+int msr_device_sync(int device) {
+    HIP_TRY(hipSetDevice(device));
+    HIP_TRY(hipDeviceSynchronize());
+    return MSR_OK;
 }
 
 }  // extern "C"

@@ -87,7 +87,11 @@ struct DeviceIndex {
     uint32_t* d_seg_ptr = nullptr;   // [shard_ntiles][n_terms+1] absolute vec index
     uint32_t* d_postings = nullptr;  // the shard's vecs; vec v of the index lives at d_postings + (v - vec_base)*4
     uint32_t* d_dense = nullptr;     // [shard_ntiles][n_pairs][tile_docs] dense head of the shard's tiles
-    uint32_t n_pairs = 0;
+    uint32_t n_pairs = 0;            // dense-head pairs resident per tile (all of them, or those with an owned term)
+    std::vector<int32_t> pair_local; // index pair p -> resident pair (or -1); identity unless the handle is a term shard
+    uint32_t seg_terms = 0;          // terms per row of d_seg_ptr (n_terms, or term_hi - term_lo on a term shard)
+    uint32_t term_base = 0;          // query term ids are rebased by this before upload (term_lo on a term shard)
+    uint64_t resident_bytes = 0;     // d_seg_ptr + d_postings + d_dense
     uint32_t vec_base = 0;
     uint64_t shard_vecs = 0;
     std::vector<uint32_t> df_shard;  // postings of each term inside this shard (for algorithmic bytes)
@@ -194,5 +198,6 @@ struct msr_batch {
 };
 
 // defined in msr_device.hip
-void batch_free(msr_batch* b);
+void batch_free(msr_batch* b);          // release + unregister from the index + delete
+void batch_release_device(msr_batch* b); // device buffers and events only (the index is being closed)
 extern "C" int batch_search_local(msr_batch* b, int k, bool final_arrays);  // internal, not part of include/msr.h

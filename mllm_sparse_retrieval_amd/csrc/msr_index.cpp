@@ -1201,7 +1201,28 @@ int msr_index_build_csr(const char* out_path, uint64_t n_docs, uint32_t n_terms,
     }
 }
 
-static int open_common(const char* path, int device, int shard, int n_shards, msr_index** out) {
+}  // extern "C"
+
+namespace msr {
+void term_bounds(const HostIndex& hx, int G, std::vector<uint32_t>& bounds) {
+    const uint32_t V = hx.h->n_terms;
+    uint64_t total = 0;
+    for (uint32_t v = 0; v < V; ++v) total += hx.df[v];
+    bounds.assign((size_t)G + 1, V);
+    bounds[0] = 0;
+    uint64_t acc = 0;
+    int g = 1;
+    for (uint32_t v = 0; v < V && g < G; ++v) {
+        acc += hx.df[v];
+        while (g < G && acc * (uint64_t)G >= total * (uint64_t)g) bounds[g++] = v + 1;
+    }
+}
+}  // namespace msr
+
+extern "C" {
+
+// by_terms = false: doc-range shard (contiguous tile range); true: term-range shard (every tile, own term range)
+static int open_common(const char* path, int device, int shard, int n_shards, msr_index** out, bool by_terms = false) {
     if (!path || !out) {
         set_error("msr_index_open: null argument");
         return MSR_E_INVAL;
@@ -1221,11 +1242,23 @@ static int open_common(const char* path, int device, int shard, int n_shards, ms
         delete ix;
         return rc;
     }
-    // doc-range shard = contiguous tile range, balanced by tile count
     const uint32_t T = ix->host.h->n_tiles;
-    uint32_t t0 = (uint32_t)((uint64_t)T * shard / n_shards), t1 = (uint32_t)((uint64_t)T * (shard + 1) / n_shards);
-    ix->shard_tile0 = t0;
-    ix->shard_ntiles = t1 - t0;
+    ix->term_hi = ix->host.h->n_terms;
+    if (by_terms) {
+        std::vector<uint32_t> tb;
+        term_bounds(ix->host, n_shards, tb);
+        ix->term_shard = shard;
+        ix->term_nshards = n_shards;
+        ix->term_lo = tb[(size_t)shard];
+        ix->term_hi = tb[(size_t)shard + 1];
+        ix->shard_tile0 = 0;
+        ix->shard_ntiles = T;
+    } else {
+        // doc-range shard = contiguous tile range, balanced by tile count
+        uint32_t t0 = (uint32_t)((uint64_t)T * shard / n_shards), t1 = (uint32_t)((uint64_t)T * (shard + 1) / n_shards);
+        ix->shard_tile0 = t0;
+        ix->shard_ntiles = t1 - t0;
+    }
     if (device >= 0) {
         rc = device_attach(ix, device);
         if (rc != MSR_OK) {
@@ -1242,6 +1275,10 @@ int msr_index_open(const char* path, int device, msr_index** out) { return open_
 
 int msr_index_open_shard(const char* path, int device, int shard, int n_shards, msr_index** out) {
     return open_common(path, device, shard, n_shards, out);
+}
+
+int msr_index_open_termshard(const char* path, int device, int shard, int n_shards, msr_index** out) {
+    return open_common(path, device, shard, n_shards, out, true);
 }
 
 void msr_index_close(msr_index* ix) {
@@ -1269,6 +1306,9 @@ int msr_index_info(const msr_index* ix, msr_info* info) {
     info->shard_ntiles = ix->shard_ntiles;
     info->device = ix->dev ? ix->device : -1;
     info->n_dense = h->n_dense;
+    info->term_lo = ix->term_lo;
+    info->term_hi = ix->term_hi;
+    info->resident_bytes = ix->dev ? device_resident_bytes(ix) : 0;
     return MSR_OK;
 }
 

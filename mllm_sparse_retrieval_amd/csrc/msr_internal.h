@@ -117,6 +117,8 @@ struct DeviceIndex;  // defined in msr_device.hip
 
 }  // namespace msr
 
+struct msr_batch;
+
 // The opaque C handle: host mmap + (optional) device residency.
 struct msr_index {
     msr::HostIndex host;
@@ -124,6 +126,15 @@ struct msr_index {
     int device = -1;
     uint32_t shard_tile0 = 0;
     uint32_t shard_ntiles = 0;
+    // term-range shard (msr_index_open_termshard): only the segments of terms [term_lo, term_hi) and the dense-head
+    // pairs that hold one of them are resident; term_nshards = 0 for handles that hold every term
+    int term_shard = -1;
+    int term_nshards = 0;
+    uint32_t term_lo = 0;
+    uint32_t term_hi = 0;  // set to n_terms at open
+    // batches created on this handle and not destroyed yet: msr_index_close releases their device buffers and
+    // detaches them (a later msr_batch_destroy only frees the host object), so the order of the two calls is free
+    std::vector<msr_batch*> live_batches;
 };
 
 namespace msr {
@@ -131,6 +142,11 @@ namespace msr {
 // implemented in msr_device.hip
 int device_attach(msr_index* ix, int device);  // upload the shard [shard_tile0, shard_tile0+shard_ntiles)
 void device_detach(msr_index* ix);
+uint64_t device_resident_bytes(const msr_index* ix);  // index bytes held in HBM by this handle
+
+// Term ownership for term-range sharding: G contiguous term-id ranges balanced by postings (cumulative df), the same
+// on every rank because it depends only on the index. bounds has G+1 entries. (msr_index.cpp)
+void term_bounds(const HostIndex& hx, int G, std::vector<uint32_t>& bounds);
 
 // build options (msr_set_build_option)
 struct BuildOptions {

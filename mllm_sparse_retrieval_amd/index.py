@@ -86,10 +86,16 @@ def build_index_from_csr(out_file, doc_ptr, term, weight, n_terms, doc_ids=None,
 class SparseIndex:
     """An opened index. device >= 0: postings resident in that GPU's HBM; device = -1: metadata only (cannot search)."""
 
-    def __init__(self, path, device=0, shard=0, n_shards=1):
+    def __init__(self, path, device=0, shard=0, n_shards=1, term_shard=None):
+        """shard / n_shards: doc-range shard (contiguous tiles). term_shard=(g, G): term-range shard g of G — every
+        doc tile, but only the postings of the owned term range resident (serves the term-range protocol only)."""
         self._h = C.c_void_p()
         self.path = index_file_of(path)
-        if n_shards == 1:
+        self.term_shard = None if term_shard is None else (int(term_shard[0]), int(term_shard[1]))
+        if term_shard is not None:
+            check(lib().msr_index_open_termshard(os.fsencode(self.path), int(device), self.term_shard[0],
+                                                 self.term_shard[1], C.byref(self._h)))
+        elif n_shards == 1:
             check(lib().msr_index_open(os.fsencode(self.path), int(device), C.byref(self._h)))
         else:
             check(lib().msr_index_open_shard(os.fsencode(self.path), int(device), int(shard), int(n_shards),
@@ -106,6 +112,8 @@ class SparseIndex:
         self.shard_tile0 = int(info.shard_tile0)
         self.shard_ntiles = int(info.shard_ntiles)
         self.n_dense = int(info.n_dense)
+        self.term_lo, self.term_hi = int(info.term_lo), int(info.term_hi)
+        self.resident_bytes = int(info.resident_bytes)
 
     # ---- metadata
     def close(self):
@@ -193,6 +201,8 @@ class SparseIndex:
         return ords, sc, su, n
 
     def batch(self, q_ptr, q_term, q_w, kmax, drop_df_eq_n=True, term_shard=None):
+        if term_shard is None:
+            term_shard = self.term_shard  # a term-shard handle only takes batches of its own term range
         return QueryBatch(self, q_ptr, q_term, q_w, kmax, drop_df_eq_n, term_shard)
 
     def search_termshard_emulated(self, q_ptr, q_term, q_w, k, n_shards, drop_df_eq_n=True):
@@ -207,6 +217,12 @@ class SparseIndex:
         check(lib().msr_search_termshard_emulated(self._h, ptr(q_ptr), ptr(q_term), ptr(q_w), nq, int(k), flags,
                                                   int(n_shards), ptr(ords), ptr(sc), ptr(su), ptr(n)))
         return ords, sc, su, n
+
+    def comm_info(self):
+        """(ranks, rank, device) as the RCCL communicator of this handle reports them."""
+        a, b, c = C.c_int(), C.c_int(), C.c_int()
+        check(lib().msr_comm_info(self._h, C.byref(a), C.byref(b), C.byref(c)))
+        return a.value, b.value, c.value
 
     def merge_lists(self, ords, scores_u32, n, k):
         """Exact top-k merge (same tie rule) of `L` per-shard lists: ords/scores [L,nq,k], n [L,nq]."""
@@ -229,6 +245,32 @@ class SparseIndex:
 
     def comm_destroy(self):
         check(lib().msr_comm_destroy(self._h))
+
+
+def search_termshard_emulated_handles(shards, q_ptr, q_term, q_w, k, drop_df_eq_n=True):
+    """The term-range protocol over `shards` = [SparseIndex(path, term_shard=(g, G)) for g in range(G)] on one GPU."""
+    q_ptr, q_term, q_w = _cabi.as_csr(q_ptr, q_term, q_w)
+    nq = len(q_ptr) - 1
+    ords = np.empty((nq, k), dtype=np.uint32)
+    sc = np.empty((nq, k), dtype=np.float32)
+    su = np.empty((nq, k), dtype=np.uint32)
+    n = np.zeros(nq, dtype=np.int32)
+    hs = (C.c_void_p * len(shards))(*[s._h for s in shards])
+    check(lib().msr_search_termshard_emulated_handles(hs, len(shards), ptr(q_ptr), ptr(q_term), ptr(q_w), nq, int(k),
+                                                      MSR_F_DROP_DF_EQ_N if drop_df_eq_n else 0, ptr(ords), ptr(sc),
+                                                      ptr(su), ptr(n)))
+    return ords, sc, su, n
+
+
+def runtime_info():
+    """{'hip_runtime', 'hip_lib', 'rccl', 'rccl_header', 'rccl_lib'} of the libraries libmsr.so resolved in this process."""
+    buf = C.create_string_buffer(2048)
+    check(lib().msr_runtime_info(buf, 2048))
+    return dict(kv.split("=", 1) for kv in buf.value.decode().split())
+
+
+def device_sync(device):
+    check(lib().msr_device_sync(int(device)))
 
 
 def comm_unique_id():

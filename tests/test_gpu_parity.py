@@ -359,6 +359,84 @@ def test_term_range_shards_emulated(m, tmp_path, tile_docs):
                 sh.search_termshard_emulated(qp, qt, qw, 10, 2)
 
 
+@pytest.mark.parametrize("tile_docs,dense_max", [(4096, 16), (8192, 16), (4096, 0), (4096, 5)])
+def test_term_range_shard_handles_hold_only_their_terms(m, tmp_path, tile_docs, dense_max):
+    """msr_index_open_termshard: G handles, each resident with ONLY its term range (segment-table columns, postings
+    slices, the dense-head pairs holding an owned term); the protocol played over them == the unsharded oracle
+    result; the per-shard resident postings add up to the whole index; misuse is refused."""
+    docs, (qp, qt, qw) = helpers.synth(30000, 48, 150, 40, 3000, seed=91)
+    m.set_build_option("dense_max_terms", dense_max)
+    try:
+        path = m.build_index_from_csr(str(tmp_path / "t.idx"), *docs, 3000, tile_docs=tile_docs)
+    finally:
+        m.set_build_option("dense_max_terms", 16)
+    oix, _ = helpers.taat_oracle(docs, 3000)
+    with m.SparseIndex(path, device=0) as full:
+        seg_table = full.n_tiles * (full.n_terms + 1) * 4
+        dense_bytes = full.n_tiles * (full.n_dense // 2) * full.tile_docs * 4
+        post_bytes = full.resident_bytes - seg_table - dense_bytes
+        for G in (1, 2, 3, 8):
+            shards = [m.SparseIndex(path, device=0, term_shard=(g, G)) for g in range(G)]
+            try:
+                assert shards[0].term_lo == 0 and shards[-1].term_hi == 3000
+                assert all(a.term_hi == b.term_lo for a, b in zip(shards, shards[1:]))
+                # postings are partitioned: the shards' slices add up to the index's postings, nothing is replicated
+                part = [sh.resident_bytes - sh.n_tiles * (sh.term_hi - sh.term_lo + 1) * 4 for sh in shards]
+                assert sum(part) >= post_bytes and all(x <= post_bytes + dense_bytes for x in part)
+                if G > 1:
+                    assert max(sh.resident_bytes for sh in shards) < full.resident_bytes
+                for k in (10, 100):
+                    want = oix.search(qp, qt, qw, k, threads=8)
+                    helpers.assert_same_results(m.search_termshard_emulated_handles(shards, qp, qt, qw, k), want, k)
+                if G > 1:
+                    with pytest.raises(Exception, match="term shard"):   # partial sums are not a search result
+                        shards[1].search_csr(qp, qt, qw, 10)
+                    with pytest.raises(Exception, match="term shard"):   # handles in the wrong order
+                        m.search_termshard_emulated_handles(shards[::-1], qp, qt, qw, 10)
+            finally:
+                for sh in shards:
+                    sh.close()
+
+
+def test_term_shard_handle_rccl_single_rank(m, tmp_path):
+    docs, (qp, qt, qw) = helpers.synth(20000, 32, 80, 30, 3000, seed=93)
+    path = m.build_index_from_csr(str(tmp_path / "t1.idx"), *docs, 3000, tile_docs=4096)
+    oix, _ = helpers.taat_oracle(docs, 3000)
+    with m.SparseIndex(path, device=0, term_shard=(0, 1)) as ix:
+        ix.comm_init(1, 0, m.comm_unique_id())
+        assert ix.comm_info()[:2] == (1, 0)
+        b = ix.batch(qp, qt, qw, 10)
+        b.search(10, sharded="terms")
+        helpers.assert_same_results(b.fetch(), oix.search(qp, qt, qw, 10), 10)
+        with pytest.raises(Exception, match="term shard"):
+            b.search(10, sharded=True)
+        b.close()
+        ix.comm_destroy()
+
+
+def test_batch_outlives_its_index(m, tmp_path):
+    """Closing the index first (e.g. an assert between ix.batch() and b.close()) must not turn into a crash: the
+    batch is detached, refuses further use, and destroying it later only frees the host object."""
+    docs, (qp, qt, qw) = helpers.synth(5000, 16, 20, 10, 500, seed=7)
+    path = m.build_index_from_csr(str(tmp_path / "l.idx"), *docs, 500, tile_docs=4096)
+    ix = m.SparseIndex(path, device=0)
+    b1, b2 = ix.batch(qp, qt, qw, 10), ix.batch(qp, qt, qw, 10)
+    b1.search(10)
+    b2.search(10)
+    want = b1.fetch()
+    b2.close()                      # ordinary order for one of them
+    ix.close()                      # ... and the index goes before b1
+    with pytest.raises(Exception, match="closed"):
+        b1.search(10)
+    with pytest.raises(Exception, match="closed"):
+        b1.fetch()
+    b1.close()
+    b1.close()                      # idempotent
+    with m.SparseIndex(path, device=0) as ix2:   # the device is fine afterwards
+        got = ix2.search_csr(qp, qt, qw, 10)
+        assert all((a == b).all() for a, b in zip(got, want))
+
+
 def test_term_range_shards_rccl_single_rank(m, tmp_path):
     docs, (qp, qt, qw) = helpers.synth(20000, 32, 80, 30, 3000, seed=93)
     path = m.build_index_from_csr(str(tmp_path / "t1.idx"), *docs, 3000, tile_docs=4096)
