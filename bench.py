@@ -89,6 +89,7 @@ def parse_args(argv):
     ap.add_argument("--c4-timeout", type=float, default=900.0, help="watchdog for the 1 M-doc object at N > 1 (s)")
     ap.add_argument("--no-c3", action="store_true", help="skip the COCO-5K (config 3) extra object")
     ap.add_argument("--only-c3", action="store_true", help="(profiling) run only the COCO-5K workloads")
+    ap.add_argument("--c3-dir", choices=["both", "i2t", "t2i"], default="both", help="(profiling) one direction only")
     ap.add_argument("--no-c4", action="store_true", help="skip the 1 M-doc extra object")
     ap.add_argument("--no-term-shards", action="store_true", help="skip the term-range sharded variant at N > 1")
     ap.add_argument("--only-c4", action="store_true", help="(profiling) run only the 1 M-doc workload")
@@ -139,12 +140,17 @@ def launch_ranks(args, argv):
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     p = subprocess.run(cmd, stdout=subprocess.PIPE, env=env)
     lines = [ln for ln in p.stdout.decode("utf-8", "replace").splitlines() if ln.strip().startswith("{")]
+    rc = p.returncode
     if lines:
         print(lines[-1], flush=True)
-    elif p.returncode == 0:
+        try:  # torch.distributed.run folds every rank failure into 1: hand on the ranks' own status
+            rc = int(json.loads(lines[-1]).get("exit_status", rc)) if rc else rc
+        except Exception:
+            pass
+    elif rc == 0:
         log("[bench] ERROR: the ranks exited 0 but printed no JSON line")
         return 1
-    return p.returncode
+    return rc
 
 
 class Ranks:
@@ -220,7 +226,9 @@ _M = None
 
 def device_sync():
     """Contract: a device-wide fence on both sides of the timed region, on THIS rank's GPU: hipDeviceSynchronize
-    through libmsr.so (covers libmsr's own stream) and torch.cuda.synchronize() as the contract names it."""
+    through libmsr.so (covers libmsr's own stream) and torch.cuda.synchronize() as the contract names it. No other
+    torch GPU call is made in this process: torch's bundled kernels expect torch's own (older) HIP runtime, while the
+    process runs on the /opt/rocm runtime libmsr.so was built for."""
     _M.device_sync(_SYNC_DEVICE)
     try:
         import torch
@@ -235,30 +243,14 @@ _HBM_COPY_GBS = None
 
 
 def hbm_copy_gbs():
-    """Measured HBM bandwidth of a device-to-device copy on this rank's GPU (read + write bytes / time), quoted beside
-    the vendor peak as SURVEY.md §8d asks. torch is only the allocator and the timer here."""
+    """Measured HBM bandwidth of a 1 GiB device-to-device copy on this rank's GPU (read + write bytes / time), quoted
+    beside the vendor peak as SURVEY.md §8d asks (msr_device_copy_gbs: hipMemcpyAsync + HIP events, no torch)."""
     global _HBM_COPY_GBS
     if _HBM_COPY_GBS is None:
         try:
-            import torch
-
-            dev = torch.device("cuda", _SYNC_DEVICE)
-            n = 1 << 30
-            a = torch.empty(n, dtype=torch.uint8, device=dev)
-            b = torch.empty(n, dtype=torch.uint8, device=dev)
-            a.zero_()
-            for _ in range(2):
-                b.copy_(a)
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            reps = 8
-            for _ in range(reps):
-                b.copy_(a)
-            e1.record()
-            torch.cuda.synchronize(dev)
-            _HBM_COPY_GBS = round(2.0 * n * reps / (e0.elapsed_time(e1) * 1e-3) / 1e9, 1)
-            del a, b
-        except Exception:
+            _HBM_COPY_GBS = round(_M.device_copy_gbs(_SYNC_DEVICE), 1)
+        except Exception as e:
+            log(f"[bench] device copy measurement failed: {e}")
             _HBM_COPY_GBS = 0.0
     return _HBM_COPY_GBS or None
 
@@ -554,7 +546,7 @@ def run_headline(args, ranks, m, wlmod):
 def run_c3(args, ranks, m, wlmod):
     """configs[2]: COCO-5K both directions, ~120-nnz queries, V = 30 000, top-10, one GPU."""
     out = {}
-    for direction in ("i2t", "t2i"):
+    for direction in (("i2t", "t2i") if args.c3_dir == "both" else (args.c3_dir,)):
         wl = wlmod.coco5k(direction, threads=args.host_threads)
         tmp = tempfile.mkdtemp(prefix="msr_c3_")
         path = m.build_index_from_csr(os.path.join(tmp, "c3.idx"), *wl.docs, wl.n_terms, threads=args.host_threads)

@@ -167,6 +167,9 @@ int msr_comm_info(const msr_index* ix, int* n_ranks, int* rank, int* device);
 int msr_runtime_info(char* buf, int cap);
 /* hipDeviceSynchronize on `device` (the benchmark's device-wide fence, independent of any torch state). */
 int msr_device_sync(int device);
+/* Bandwidth of a device-to-device copy of `bytes` (read + write bytes / time, GB/s): the measured HBM figure quoted
+ * beside the vendor peak in the benchmark record. */
+int msr_device_copy_gbs(int device, uint64_t bytes, int reps, double* gbs);
 
 /* Term-range shards (the north star's partition; exact protocol of DESIGN.md §6): the batch holds only the query terms
  * of term range `shard` of `n_shards` (ranges are contiguous in term id and balanced by postings). Search = dump the

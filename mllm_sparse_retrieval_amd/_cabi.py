@@ -80,6 +80,7 @@ SYMBOLS = [
     ("msr_comm_info", _I, [_VP, C.POINTER(_I), C.POINTER(_I), C.POINTER(_I)]),
     ("msr_runtime_info", _I, [_VP, _I]),
     ("msr_device_sync", _I, [_I]),
+    ("msr_device_copy_gbs", _I, [_I, _U64, _I, C.POINTER(C.c_double)]),
     ("msr_merge_lists", _I, [_VP, _I, _I, _I, _VP, _VP, _VP, _VP, _VP, _VP, _VP]),
     ("msr_dense_open", _I, [_VP, _U64, _U32, _I, C.POINTER(_VP)]),
     ("msr_dense_search", _I, [_VP, _VP, _I, _I, _VP, _VP, _VP, C.POINTER(C.c_float), C.POINTER(C.c_float)]),

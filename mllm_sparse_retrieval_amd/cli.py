@@ -5,9 +5,16 @@
     python -m mllm_sparse_retrieval_amd search --sparse_index out/ --depth 10 --query_type text \\
            --dataset_name flickr --queries out/query.tsv --qrels out/qrels.csv --save_dir runs/   (search_sparse.sh)
 
+    python -m mllm_sparse_retrieval_amd eval   --runs_dir runs/ --qrels out/qrels.csv --dataset_name flickr \
+           --query_type text [--compat-denominator --world_size 4]                                (recall of TREC runs)
+
 `encode` writes exactly the files src/encode.py:412-426 writes (corpus_{shard}.jsonl, query.tsv); `index` accepts and
 ignores pyserini's --collection/--generator/--impact/--pretokenized; `search` prints recall in the reference's format
-(src/metrices.py:103-137) and writes TREC runs (src/hybrid.py:20-29) under --save_dir.
+(src/metrices.py:103-137) and writes TREC runs (src/hybrid.py:20-29) under --save_dir. Under a launcher
+(`python -m torch.distributed.run --nproc-per-node N -m mllm_sparse_retrieval_amd search ...`, the counterpart of
+`deepspeed --num_gpus=4 src/search.py`, scripts/search_sparse.sh:14) `search` is the reference's DP over queries
+(src/search.py:180-182): every rank opens the index on its own GPU, searches its DistributedSampler shard of the
+queries, and only recall fractions are gathered (src/metrices.py:86-100). `eval` is the recall reporter on its own.
 """
 from __future__ import annotations
 
@@ -121,10 +128,27 @@ def _cmd_search(a):
         dense_retriever.add(p_reps)
         q_reps, q_lookup = pickle_load(os.path.join(a.passage_reps, "query.pkl"))
         q_reps_by_id = {str(i): r for i, r in zip(q_lookup, q_reps)}
+    # one process per GPU under a launcher (src/search.py:115-129); gloo carries the recall fractions only
+    world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if not dist.is_initialized():
+            dist.init_process_group("gloo")
+        a.device = int(os.environ.get("LOCAL_RANK", "0"))
     searcher = LuceneImpactSearcher(os.path.join(a.sparse_index, "index") if os.path.isdir(
         os.path.join(a.sparse_index, "index")) else a.sparse_index, None, device=a.device)
     searcher.set_analyzer(JWhiteSpaceAnalyzer())
     qids, texts = read_queries(a.queries or os.path.join(a.sparse_index, "query.tsv"))
+    n_queries = len(qids)
+    if world > 1:  # the reference's DistributedSampler split, padding included (src/search.py:180-182)
+        from .sampler import distributed_sampler_indices
+
+        pos = distributed_sampler_indices(n_queries, world, rank)
+        if not a.compat_denominator:  # every query once: drop the padded repeats
+            pos = [p for j, p in enumerate(pos) if rank + j * world < n_queries]
+        qids, texts = [qids[p] for p in pos], [texts[p] for p in pos]
     bs = a.batch_size if a.batch_size > 0 else len(qids)
     args = SimpleNamespace(depth=a.depth, threads=a.threads, query_type=a.query_type)
     sparse_run, dense_run, fusion_run = {}, {}, {}
@@ -147,16 +171,70 @@ def _cmd_search(a):
         print(f"search: {len(qids)} queries in {dt:.3f}s ({len(qids) / max(dt, 1e-9):.0f} q/s end-to-end incl. host)")
     if a.save_dir:
         os.makedirs(a.save_dir, exist_ok=True)
-        write_trec_run(sparse_run, os.path.join(a.save_dir, "sparse.trec"), name="sparse")
+        sfx = f".rank{rank}" if world > 1 else ""
+        write_trec_run(sparse_run, os.path.join(a.save_dir, "sparse.trec" + sfx), name="sparse")
         if dense_run:
-            write_trec_run(dense_run, os.path.join(a.save_dir, "dense.trec"), name="dense")
-            write_trec_run(fusion_run, os.path.join(a.save_dir, "fusion.trec"))
+            write_trec_run(dense_run, os.path.join(a.save_dir, "dense.trec" + sfx), name="dense")
+            write_trec_run(fusion_run, os.path.join(a.save_dir, "fusion.trec" + sfx))
+        if world > 1:  # rank 0 joins the per-rank files (one node, shared directory)
+            dist.barrier()
+            if rank == 0:
+                for name in ("sparse.trec", "dense.trec", "fusion.trec"):
+                    parts = [os.path.join(a.save_dir, f"{name}.rank{r}") for r in range(world)]
+                    if all(os.path.exists(p) for p in parts):
+                        done = set()  # queries an earlier rank's file already holds (the sampler's padded repeats)
+                        with open(os.path.join(a.save_dir, name), "w") as out:
+                            for p in parts:
+                                mine = set()
+                                for line in open(p):
+                                    qid = line.split(" ", 1)[0]
+                                    if qid in done:
+                                        continue
+                                    mine.add(qid)
+                                    out.write(line)
+                                done |= mine
+                        for p in parts:
+                            os.remove(p)
     if a.qrels:
         ds = CrossModalQrels(a.qrels, a.dataset_name)
-        m = RecallMetrics(ds, dense_run, sparse_run, fusion_run, p_lookup or [], qids, args)
+        m = RecallMetrics(ds, dense_run, sparse_run, fusion_run, p_lookup or [], qids, args,
+                          denominator=None if (a.compat_denominator or world == 1) else n_queries)
         m.sort_and_count()
         m.all_gather_object()
         m.print_recall()
+    searcher.close()
+    if world > 1:
+        dist.barrier()
+
+
+def _cmd_eval(a):
+    """Standalone recall reporter over TREC runs: sparse/dense/fusion.trec (src/hybrid.py:8-29
+    format) + the dataset csv -> the reference's print-out (src/metrices.py:103-137). Default denominator: the true
+    number of queries; --compat-denominator replays --world_size ranks of the reference (DistributedSampler shards,
+    padded repeats searched and counted twice, len(lookup_indices) * world, src/metrices.py:92)."""
+    from .fusion import read_trec_run
+    from .qrels import CrossModalQrels
+    from .recall import replay_ranks
+
+    def load(explicit, name):
+        path = explicit or (os.path.join(a.runs_dir, name) if a.runs_dir else None)
+        return read_trec_run(path) if path and os.path.exists(path) else {}
+
+    sparse_run, dense_run = load(a.sparse_run, "sparse.trec"), load(a.dense_run, "dense.trec")
+    fusion_run = {q: v["docs"] for q, v in load(a.fusion_run, "fusion.trec").items()}  # no 'docs' level (src/metrices.py:70-73)
+    if not (sparse_run or dense_run or fusion_run):
+        sys.exit("eval: no run file found (--runs_dir with sparse.trec / dense.trec / fusion.trec, or --sparse_run ...)")
+    ds = CrossModalQrels(a.qrels, a.dataset_name)
+    # the query universe in dataset order: captions ('full' mode) or images ('single'), src/dataset.py:104-110
+    query_ids = ds.text_id_list if a.query_type == "text" else ds.img_id_list
+    if a.queries:
+        query_ids = read_queries(a.queries)[0]
+    look_up = sorted({d for v in dense_run.values() for d in v["docs"]})
+    args = SimpleNamespace(query_type=a.query_type)
+    world = a.world_size if a.compat_denominator else 1
+    m = replay_ranks(ds, dense_run, sparse_run, fusion_run, look_up, query_ids, args, world, compat=a.compat_denominator)
+    m.print_recall()
+    return m
 
 
 def main(argv=None):
@@ -201,7 +279,23 @@ def main(argv=None):
     s.add_argument("--queries", default=None)
     s.add_argument("--qrels", default=None)
     s.add_argument("--device", type=int, default=0)
+    s.add_argument("--compat-denominator", "--compat_denominator", dest="compat_denominator", action="store_true",
+                   help="multi-rank: keep the sampler's padded repeats and divide by len(shard) * world like the reference")
     s.set_defaults(fn=_cmd_search)
+
+    v = sub.add_parser("eval")
+    v.add_argument("--runs_dir", default=None)
+    v.add_argument("--sparse_run", default=None)
+    v.add_argument("--dense_run", default=None)
+    v.add_argument("--fusion_run", default=None)
+    v.add_argument("--qrels", required=True, help="dataset csv (data/flickr/flickr_test.csv schema, src/dataset.py:86-102)")
+    v.add_argument("--dataset_name", default="flickr")
+    v.add_argument("--query_type", default="text")
+    v.add_argument("--queries", default=None, help="query.tsv giving the query universe / order (default: the csv's)")
+    v.add_argument("--compat-denominator", "--compat_denominator", dest="compat_denominator", action="store_true")
+    v.add_argument("--world_size", type=int, default=4, help="ranks to replay with --compat-denominator "
+                                                             "(scripts/search_sparse.sh:14 uses 4)")
+    v.set_defaults(fn=_cmd_eval)
 
     a = ap.parse_args(argv)
     a.fn(a)

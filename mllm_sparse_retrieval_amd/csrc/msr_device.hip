@@ -1411,4 +1411,37 @@ int msr_device_sync(int device) {
     return MSR_OK;
 }
 
+int msr_device_copy_gbs(int device, uint64_t bytes, int reps, double* gbs) {
+    if (!gbs || bytes == 0 || reps < 1) {
+        set_error("msr_device_copy_gbs: bad argument");
+        return MSR_E_INVAL;
+    }
+    HIP_TRY(hipSetDevice(device));
+    void *a = nullptr, *b = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    hipStream_t st = nullptr;
+    int rc = MSR_OK;
+    float ms = 0;
+    bool ok = hipMalloc(&a, bytes) == hipSuccess && hipMalloc(&b, bytes) == hipSuccess &&
+              hipStreamCreateWithFlags(&st, hipStreamNonBlocking) == hipSuccess && hipEventCreate(&e0) == hipSuccess &&
+              hipEventCreate(&e1) == hipSuccess && hipMemsetAsync(a, 0, bytes, st) == hipSuccess;
+    for (int i = 0; i < 2 && ok; ++i) ok = hipMemcpyAsync(b, a, bytes, hipMemcpyDeviceToDevice, st) == hipSuccess;
+    ok = ok && hipEventRecord(e0, st) == hipSuccess;
+    for (int i = 0; i < reps && ok; ++i) ok = hipMemcpyAsync(b, a, bytes, hipMemcpyDeviceToDevice, st) == hipSuccess;
+    ok = ok && hipEventRecord(e1, st) == hipSuccess && hipStreamSynchronize(st) == hipSuccess &&
+         hipEventElapsedTime(&ms, e0, e1) == hipSuccess;
+    if (!ok || ms <= 0) {
+        set_error("device copy measurement failed: %s", hipGetErrorString(hipGetLastError()));
+        rc = MSR_E_HIP;
+    } else {
+        *gbs = 2.0 * (double)bytes * reps / (ms * 1e-3) / 1e9;  // read + write
+    }
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    if (st) (void)hipStreamDestroy(st);
+    if (a) (void)hipFree(a);
+    if (b) (void)hipFree(b);
+    return rc;
+}
+
 }  // extern "C"

@@ -273,6 +273,13 @@ def device_sync(device):
     check(lib().msr_device_sync(int(device)))
 
 
+def device_copy_gbs(device, nbytes=1 << 30, reps=8):
+    """Measured bandwidth of a device-to-device copy (read + write bytes / time, GB/s)."""
+    g = C.c_double()
+    check(lib().msr_device_copy_gbs(int(device), int(nbytes), int(reps), C.byref(g)))
+    return g.value
+
+
 def comm_unique_id():
     buf = C.create_string_buffer(_cabi.MSR_COMM_ID_BYTES)
     check(lib().msr_comm_unique_id(buf))

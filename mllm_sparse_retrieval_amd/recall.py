@@ -23,11 +23,17 @@ def _dist():
 
 
 class RecallMetrics:
-    def __init__(self, dataset, dense_run, sparse_run, fusion_run, look_up, lookup_indices, search_args):
+    def __init__(self, dataset, dense_run, sparse_run, fusion_run, look_up, lookup_indices, search_args,
+                 denominator=None, world_size=None, rank=None):
+        """denominator: None = the reference's len(lookup_indices) * world_size (src/metrices.py:92, which counts the
+        sampler's padding twice); an int = that many queries (the true query count of a sharded run).
+        world_size / rank: override the process group (the `eval` step replays W ranks in one process)."""
         self.recall_k_setting_list = list(RECALL_KS)
-        d = _dist()
-        self.world_size = d.get_world_size() if d else 1
-        self.rank = d.get_rank() if d else 0
+        d = _dist() if world_size is None else None
+        self.world_size = world_size if world_size is not None else (d.get_world_size() if d else 1)
+        self.rank = rank if rank is not None else (d.get_rank() if d else 0)
+        self._dist = d
+        self.denominator = denominator
         ks = self.recall_k_setting_list
         self.dense_counts = {k: 0 for k in ks}
         self.sparse_counts = {k: 0 for k in ks}
@@ -68,8 +74,9 @@ class RecallMetrics:
                 self._count(counts, self._sort(docs), target)
 
     def all_gather_object(self):
-        denom = len(self.lookup_indices) * self.world_size
-        d = _dist()
+        denom = self.denominator if self.denominator is not None else len(self.lookup_indices) * self.world_size
+        denom = max(denom, 1)
+        d = self._dist
         for counts_name, lists in (("dense_counts", self.dense_recall_lists), ("sparse_counts", self.sparse_recall_lists),
                                    ("fusion_counts", self.fusion_recall_lists)):
             counts = {k: getattr(self, counts_name)[k] / denom for k in self.recall_k_setting_list}
@@ -78,7 +85,7 @@ class RecallMetrics:
                 if d:
                     d.all_gather_object(object_list=lists[k], obj=counts[k])
                 else:
-                    lists[k][0] = counts[k]
+                    lists[k][self.rank] = counts[k]  # (a replayed rank fills its own slot)
 
     def recalls(self):
         """{'dense'|'sparse'|'fusion': {k: recall summed over ranks}} for the runs that are present."""
@@ -93,7 +100,7 @@ class RecallMetrics:
     def print_recall(self):
         if self.rank != 0:
             return
-        print(len(self.lookup_indices) * self.world_size)
+        print(self.denominator if self.denominator is not None else len(self.lookup_indices) * self.world_size)
         labels = (("dense", "Dense recall @ {}: {}", "Dense reps recall", self.dense_run, self.dense_recall_lists),
                   ("sparse", "Sparse recall @ {}: {}", "Sparse reps recall", self.sparse_run, self.sparse_recall_lists),
                   ("fusion", "Fusion/Hybrid recall @ {}: {}", "Fusion/Hybrid reps recall", self.fusion_run,
@@ -108,3 +115,34 @@ class RecallMetrics:
                 print(per_k.format(k, lists[k]))
             print("{}: r@1 {}, r@5 {}, r@10 {}, r@100 {}, r@200 {}".format(summary, total[1], total[5], total[10],
                                                                            total[100], total[200]))
+
+
+def replay_ranks(dataset, dense_run, sparse_run, fusion_run, look_up, query_ids, search_args, world_size, compat=True):
+    """Recall of complete runs as `world_size` ranks of the reference would have reported it (src/search.py:180-182 +
+    src/metrices.py:86-100), replayed in one process: rank r owns the DistributedSampler shard of `query_ids`
+    (padding included), counts its hits and divides by len(shard) * world_size (compat) or by the true query count.
+    Returns the rank-0 RecallMetrics object with every rank's fractions in its lists (print_recall() works on it)."""
+    from .sampler import shard_query_ids
+
+    n = len(query_ids)
+    first = None
+    for r in range(world_size):
+        shard = shard_query_ids(query_ids, world_size, r) if world_size > 1 else list(query_ids)
+        if not compat:  # the true denominator: every query once — drop the sampler's padding
+            total = -(-n // world_size) * world_size
+            shard = [q for j, q in enumerate(shard) if r + j * world_size < n] if total != n else shard
+        mine = set(shard)
+        pick = lambda run: {q: v for q, v in run.items() if q in mine}  # noqa: E731
+        m = RecallMetrics(dataset, pick(dense_run), pick(sparse_run), pick(fusion_run), look_up, shard, search_args,
+                          denominator=None if compat else n, world_size=world_size, rank=r)
+        m.sort_and_count()
+        m.all_gather_object()
+        if first is None:
+            first = m
+        else:
+            for lists_name in ("dense_recall_lists", "sparse_recall_lists", "fusion_recall_lists"):
+                for k in m.recall_k_setting_list:
+                    getattr(first, lists_name)[k][r] = getattr(m, lists_name)[k][r]
+    # runs that are empty on rank 0 but not overall still print
+    first.dense_run, first.sparse_run, first.fusion_run = dense_run, sparse_run, fusion_run
+    return first

@@ -3,6 +3,7 @@
 """
 from __future__ import annotations
 
+import io
 import pickle
 
 import numpy as np
@@ -42,8 +43,39 @@ def search_queries(retriever, q_reps, p_lookup, args):
     return all_scores, psg_indices
 
 
+# What a (reps, lookup) file of the encode step needs to come back to life (src/encode.py:405-410 pickles
+# `(np.ndarray, list[str])`): the numpy array reconstructors and nothing else. Containers, str, int, float, bytes are
+# pickle opcodes, not globals. Any other global — i.e. anything that could run code — is refused.
+_PICKLE_ALLOWED = {
+    ("numpy.core.multiarray", "_reconstruct"), ("numpy._core.multiarray", "_reconstruct"),
+    ("numpy.core.multiarray", "scalar"), ("numpy._core.multiarray", "scalar"),
+    ("numpy.core.numeric", "_frombuffer"), ("numpy._core.numeric", "_frombuffer"),
+    ("numpy", "ndarray"), ("numpy", "dtype"),
+    ("_codecs", "encode"),  # protocol <= 2 carries an array's bytes as a latin-1 string
+}
+
+
+class _RepsUnpickler(pickle.Unpickler):
+    def find_class(self, module, name):
+        if (module, name) in _PICKLE_ALLOWED:
+            return super().find_class(module, name)
+        raise pickle.UnpicklingError(f"refused global '{module}.{name}': a reps file may only hold numpy arrays, "
+                                     f"lists, tuples, str, int and float")
+
+    def persistent_load(self, pid):
+        raise pickle.UnpicklingError("refused persistent id in a reps file")
+
+
 def pickle_load(path):
-    """src/search.py:49-52: (reps, lookup) written by the encode step. Only for files this package wrote itself."""
+    """src/search.py:49-52: (reps, lookup) written by the encode step (src/encode.py:405-410) — read with an unpickler
+    that executes nothing from the file: only numpy array reconstruction is allowed, so a reference-written
+    corpus*.pkl / query.pkl loads and anything else raises pickle.UnpicklingError."""
     with open(path, "rb") as f:
-        reps, lookup = pickle.load(f)
-    return np.array(reps), lookup
+        obj = _RepsUnpickler(io.BytesIO(f.read())).load()
+    if not (isinstance(obj, tuple) and len(obj) == 2):
+        raise pickle.UnpicklingError("a reps file holds a (reps, lookup) pair")
+    reps, lookup = obj
+    reps = np.array(reps)
+    if reps.dtype == object:
+        raise pickle.UnpicklingError("reps must be a numeric array")
+    return reps, lookup

@@ -6,6 +6,7 @@ import json
 import os
 from types import SimpleNamespace
 
+import numpy as np
 import pytest
 
 from mllm_sparse_retrieval_amd import fusion, run
@@ -123,3 +124,112 @@ def test_cli_query_readers(tmp_path):
     j = tmp_path / "q.jsonl"
     j.write_text('{"id": 5, "vector": {"dog": 2, "cat": 1, "zero": 0}}\n')
     assert read_queries(str(j)) == (["5"], ["dog dog cat "]) or read_queries(str(j))[1][0].split() == ["dog", "dog", "cat"]
+
+
+# ------------------------------------------------------------------------------------------------ reps files
+def test_pickle_load_reads_reps_files_without_executing_anything(tmp_path):
+    """pickle_load (src/search.py:49-52) on files like src/encode.py:405-410 writes — (float32 [N,H], list of ids) —
+    in every protocol; a pickle that names any other global (here: os.system) is refused, not run."""
+    import pickle
+
+    from mllm_sparse_retrieval_amd.run import pickle_load
+
+    reps = np.arange(12, dtype=np.float32).reshape(3, 4)
+    for proto in (2, 3, 4, 5):
+        f = tmp_path / f"corpus_{proto}.pkl"
+        with open(f, "wb") as fh:
+            pickle.dump((reps, ["10", "11", "12"]), fh, protocol=proto)
+        got, lookup = pickle_load(str(f))
+        assert got.dtype == np.float32 and (got == reps).all() and lookup == ["10", "11", "12"]
+    with open(tmp_path / "ints.pkl", "wb") as fh:  # ids as ints / numpy scalars, reps as a list of rows
+        pickle.dump(([[1.0, 2.0], [3.0, 4.0]], [np.int64(7), 8]), fh)
+    got, lookup = pickle_load(str(tmp_path / "ints.pkl"))
+    assert got.shape == (2, 2) and [int(x) for x in lookup] == [7, 8]
+
+    marker = tmp_path / "pwned"
+
+    class Evil:
+        def __reduce__(self):
+            import os
+
+            return (os.system, (f"touch {marker}",))
+
+    with open(tmp_path / "evil.pkl", "wb") as fh:
+        pickle.dump((Evil(), []), fh)
+    with pytest.raises(pickle.UnpicklingError, match="refused global"):
+        pickle_load(str(tmp_path / "evil.pkl"))
+    assert not marker.exists()
+    with open(tmp_path / "obj.pkl", "wb") as fh:
+        pickle.dump((np.array([{"a": 1}], dtype=object), []), fh)
+    with pytest.raises(pickle.UnpicklingError):
+        pickle_load(str(tmp_path / "obj.pkl"))
+    with open(tmp_path / "shape.pkl", "wb") as fh:
+        pickle.dump([1, 2, 3], fh)
+    with pytest.raises(pickle.UnpicklingError, match="pair"):
+        pickle_load(str(tmp_path / "shape.pkl"))
+
+
+# ------------------------------------------------------------------------------------------------ sampler / eval
+@pytest.mark.parametrize("n,world", [(35, 4), (36, 4), (5, 4), (25010, 4), (1, 2), (7, 8), (10, 1)])
+def test_sampler_restatement_equals_torch_distributed_sampler(n, world):
+    from torch.utils.data import DistributedSampler
+
+    from mllm_sparse_retrieval_amd.sampler import distributed_sampler_indices
+
+    for rank in range(world):
+        want = list(DistributedSampler(range(n), num_replicas=world, rank=rank, shuffle=True))  # seed 0, epoch 0
+        assert distributed_sampler_indices(n, world, rank) == want
+        want = list(DistributedSampler(range(n), num_replicas=world, rank=rank, shuffle=False))
+        assert distributed_sampler_indices(n, world, rank, shuffle=False) == want
+
+
+def test_eval_subcommand_true_and_compat_denominator(tmp_path, capsys):
+    """`eval` over TREC runs + the dataset csv (fixture: the first 35 rows of data/flickr/flickr_test.csv = 7 images x 5
+    captions): true-nq denominator by default; --compat-denominator replays the reference's 4 ranks — 35 captions are
+    padded to 36, the repeated caption is searched and counted on two ranks, every rank divides by 9 * 4
+    (src/metrices.py:92, src/search.py:180-182)."""
+    from torch.utils.data import DistributedSampler
+
+    from mllm_sparse_retrieval_amd import cli
+    from mllm_sparse_retrieval_amd.fusion import write_trec_run
+    from mllm_sparse_retrieval_amd.qrels import CrossModalQrels
+
+    csv_path = os.path.join(os.path.dirname(__file__), "golden", "flickr_test_head.csv")
+    ds = CrossModalQrels(csv_path, "flickr")
+    caps = ds.text_id_list
+    assert len(caps) == 35 and len(ds.img_id_list) == 7
+    imgs = ds.img_id_list
+    # a sparse run: caption j ranks its own image at position (j % 4) + 1 among other images; every 7th caption misses
+    run = {}
+    for j, c in enumerate(caps):
+        own = ds.get_target(c, "text")
+        others = [i for i in imgs if i != own]
+        ranked = others[: j % 4] + ([own] if j % 7 else []) + others[j % 4:]
+        run[c] = {"docs": {d: 100.0 - r for r, d in enumerate(ranked[:6])}}
+    os.makedirs(tmp_path / "runs")
+    write_trec_run(run, str(tmp_path / "runs" / "sparse.trec"), name="sparse")
+
+    def hit_at(c, k):
+        ranked = sorted(run[c]["docs"].items(), key=lambda kv: kv[1], reverse=True)[:k]
+        return ds.get_target(c, "text") in [d for d, _ in ranked]
+
+    cli.main(["eval", "--runs_dir", str(tmp_path / "runs"), "--qrels", csv_path, "--dataset_name", "flickr",
+              "--query_type", "text"])
+    out = capsys.readouterr().out.splitlines()
+    r1, r5 = sum(hit_at(c, 1) for c in caps) / 35, sum(hit_at(c, 5) for c in caps) / 35
+    assert out[0] == "35" and out[1] == f"Sparse recall @ 1: [{r1}]"
+    assert out[-1].startswith(f"Sparse reps recall: r@1 {r1}, r@5 {r5}, ")
+
+    cli.main(["eval", "--runs_dir", str(tmp_path / "runs"), "--qrels", csv_path, "--dataset_name", "flickr",
+              "--query_type", "text", "--compat-denominator", "--world_size", "4"])
+    out = capsys.readouterr().out.splitlines()
+    per_rank = []
+    for rank in range(4):
+        shard = [caps[i] for i in DistributedSampler(range(35), num_replicas=4, rank=rank, shuffle=True)]
+        assert len(shard) == 9
+        per_rank.append(sum(hit_at(c, 1) for c in set(shard)) / (9 * 4))
+    assert out[0] == "36" and out[1] == f"Sparse recall @ 1: {per_rank}"
+    assert out[-1].startswith(f"Sparse reps recall: r@1 {sum(per_rank)}, ")
+    # the padded repeat is counted twice: compat != true whenever the repeated caption is a hit
+    rep = [caps[i] for i in DistributedSampler(range(35), num_replicas=4, rank=3, shuffle=True)][-1]
+    assert (sum(per_rank) * 36 - r1 * 35) == pytest.approx(1.0 if hit_at(rep, 1) else 0.0)
