@@ -1,7 +1,8 @@
 // Hybrid path and encode-side sparsifier: the dense fp16 MFMA scorer (dense_scores), the reference's min-max fusion on
 // the GPU (fuse_tiles), the log1p-relu top-k sparsifier (sparsify_keys), and their C-ABI entry points. Selection and
 // list merging reuse the search path's kernels (launch_select / launch_merge, msr_device.hip).
-#include "msr_select.hpp"
+#include "msr_accumulate.hpp"
+#include "msr_hist_select.hpp"
 
 using namespace msr;
 
@@ -204,6 +205,11 @@ struct msr_dense {
     uint32_t h = 0;
     uint32_t tile_docs = 0;
     uint32_t n_tiles = 0;
+    // hybrid path on single-tile indexes: the same rows in doc-ORDINAL order (P_ord[row2ord[r]] = P[r]), built on first
+    // use and kept while the mapping stays the same
+    _Float16* d_P_ord = nullptr;
+    std::vector<uint32_t> ord_map;
+    bool lds_attr_set = false;  // dense_scores_256 needs the 128 KiB dynamic-LDS opt-in once per device
 };
 
 extern "C" {
@@ -252,9 +258,36 @@ int msr_dense_open(const uint16_t* p_fp16, uint64_t n, uint32_t h, int device, m
 void msr_dense_close(msr_dense* dx) {
     if (!dx) return;
     (void)hipSetDevice(dx->device);
+    if (dx->d_P_ord) (void)hipFree(dx->d_P_ord);
     if (dx->d_P) (void)hipFree(dx->d_P);
     if (dx->stream) (void)hipStreamDestroy(dx->stream);
     delete dx;
+}
+
+// C = Q * P^T as order-preserving keys into out[q][ld] for doc columns [0, n_cover); rows of Q padded to qn_pad (a
+// multiple of 256), P rows readable up to n_cover. Doc blocks are launched in slices of at most 65535 (grid y limit).
+static int launch_dense_gemm(msr_dense* dx, const _Float16* P, const _Float16* d_Q, uint32_t* d_S, uint32_t qn,
+                             uint32_t qn_pad, uint64_t n_cover, uint64_t ld, hipStream_t st, bool force_256 = false) {
+    const bool big = dx->h % 64 == 0 && n_cover % 256 == 0 &&
+                     (force_256 || (uint64_t)(qn_pad / 256) * (n_cover / 256) >= 256);
+    if (big && !dx->lds_attr_set) {  // 128 KiB of dynamic LDS needs the opt-in (per device: kept in the handle)
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(dense_scores_256),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 2 * kG2Stage));
+        dx->lds_attr_set = true;
+    }
+    const uint64_t blk = big ? 256 : 128;
+    for (uint64_t d0 = 0; d0 < n_cover; d0 += blk * kMaxGridY) {
+        const uint64_t nd = std::min<uint64_t>(n_cover - d0, blk * kMaxGridY);
+        const uint32_t n_left = dx->n > d0 ? (uint32_t)std::min<uint64_t>(dx->n - d0, 0xFFFFFFFFull) : 0u;
+        if (big)
+            hipLaunchKernelGGL(dense_scores_256, dim3(qn_pad / 256, (uint32_t)(nd / 256)), dim3(512), 2 * kG2Stage, st, d_Q,
+                               P + d0 * dx->h, d_S + d0, qn, n_left, dx->h, ld);
+        else
+            hipLaunchKernelGGL(dense_scores, dim3(qn_pad / 128, (uint32_t)(nd / 128)), dim3(256), 0, st, d_Q, P + d0 * dx->h,
+                               d_S + d0, qn, n_left, dx->h, ld);
+        HIP_TRY(hipGetLastError());
+    }
+    return MSR_OK;
 }
 
 // to_device = true: out_* are DEVICE buffers ([nq][k] / [nq]) filled on dx->stream (hybrid path); else host buffers.
@@ -309,19 +342,8 @@ static int dense_search_impl(msr_dense* dx, const uint16_t* q_fp16, int nq, int 
         // the select instance: 1024 docs at 4096-doc tiles, 2048 at 8192); padding beyond that is never read
         const uint64_t round_docs = dx->tile_docs == 4096 ? 1024 : 2048;
         const uint64_t n_cover = std::min<uint64_t>(dx->n_pad, (dx->n + round_docs - 1) / round_docs * round_docs);
-        if (dx->h % 64 == 0 && n_cover % 256 == 0 && (uint64_t)(qn_pad / 256) * (n_cover / 256) >= 256) {
-            static bool lds_set = false;  // 128 KiB of dynamic LDS needs the opt-in (once per process)
-            if (!lds_set) {
-                HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(dense_scores_256),
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, 2 * kG2Stage));
-                lds_set = true;
-            }
-            hipLaunchKernelGGL(dense_scores_256, dim3(qn_pad / 256, (uint32_t)(n_cover / 256)), dim3(512), 2 * kG2Stage,
-                               dx->stream, d_Q, dx->d_P, d_S, qn, (uint32_t)dx->n, dx->h, dx->n_pad);
-        } else {
-            hipLaunchKernelGGL(dense_scores, dim3(qn_pad / 128, (uint32_t)(n_cover / 128)), dim3(256), 0, dx->stream, d_Q,
-                               dx->d_P, d_S, qn, (uint32_t)dx->n, dx->h, dx->n_pad);
-        }
+        rc = launch_dense_gemm(dx, dx->d_P, d_Q, d_S, qn, qn_pad, n_cover, dx->n_pad, dx->stream);
+        if (rc != MSR_OK) break;
         (void)hipEventRecord(e1, dx->stream);
         SelectArgs se;
         se.unsorted = 0;
@@ -518,6 +540,349 @@ __global__ __launch_bounds__(NT) void fuse_tiles(const FuseArgs a) {
 
 }  // namespace msr
 
+// ================================================================================================ fused hybrid tile
+// Single-tile indexes (n_docs <= 8192: BASELINE config 5 is COCO-5K's 5 000 images): ONE workgroup per query does the
+// whole of  sparse top-`depth`  +  dense top-`depth`  +  fuse()  +  top-k  (src/search.py:55-63,85-99,455-461,
+// src/hybrid.py:32-53) without a list ever leaving the CU:
+//   1. accumulate_tile: the query's exact integer scores against the tile, in LDS (the search path's own phase);
+//   2. every thread takes its 16 accumulators and the same 16 docs' dense scores (one row of the GEMM's output, written
+//      in ORDINAL order because the GEMM ran on the ordinal-permuted passage matrix) into registers;
+//   3. hist_threshold twice: the composite of the depth-th best sparse score and of the depth-th best dense score —
+//      list MEMBERSHIP is all fuse() needs (min = the depth-th score, max = the best, "doc in run");
+//   4. fused score per doc from registers -> LDS tile of order-preserving keys -> tile_select(k) -> result arrays.
+// What this replaces: tile_select at k = 1000 inside score_tiles, select_tiles over the 500 MB score matrix,
+// fuse_tiles re-reading 2 x 25 010 x 1000 keys, and three list merges.
+namespace msr {
+
+struct HybridArgs {
+    const uint32_t* dkeys;    // [qn][ld] order-preserving keys of the dense scores of queries q0 .. q0+qn-1, by ORDINAL
+    uint64_t ld;
+    const int32_t* self_ord;  // [nq] ordinal to skip (remove_query) or -1; may be null
+    uint32_t depth, k;
+    float w_dense, w_sparse;
+    uint32_t* out_ord;        // [nq][k]
+    float* out_score;         // [nq][k] fused scores
+    int32_t* out_n;           // [nq]
+};
+
+template <int TILE_DOCS, int NT, int U, int MIN_WAVES, bool DBG = false>
+__global__ __launch_bounds__(NT, MIN_WAVES) void hybrid_tiles(const ScoreArgs a, const HybridArgs h) {
+    constexpr int CAND = 1024;
+    constexpr int E = TILE_DOCS / NT, R = E / 4;
+    using L = TileLds<TILE_DOCS, NT, CAND>;
+    static_assert(L::kUnion >= kHistBins * 4 + kHistCand * 8, "histogram + candidates share the select union");
+    static_assert(L::kTmax >= (int)sizeof(HistScratch), "the selection scratch lives in the maxima region");
+    __shared__ __attribute__((aligned(16))) uint8_t lds[L::kTotal];
+    __shared__ uint64_t res[64];
+    uint32_t* const acc = reinterpret_cast<uint32_t*>(lds);
+    uint8_t* const un = lds + L::kAcc;
+    uint64_t* const cand = reinterpret_cast<uint64_t*>(un);
+    uint32_t* const tmax = reinterpret_cast<uint32_t*>(un + L::kUnion);
+    uint32_t* const wmax = tmax + NT;
+    SelectScratch& ss = *reinterpret_cast<SelectScratch*>(un + L::kUnion + L::kTmax);
+    uint32_t* const hist = reinterpret_cast<uint32_t*>(un);
+    uint64_t* const hcand = reinterpret_cast<uint64_t*>(un + kHistBins * 4);
+    HistScratch& hs = *reinterpret_cast<HistScratch*>(tmax);
+
+    const uint32_t tid = threadIdx.x;
+    // diagnostic instance only (MSR_DEBUG_HYBRID): wave 0 of one workgroup in 64 adds its clock deltas per phase
+    long long t_prev = 0;
+    auto stamp = [&](int slot) {
+        if (DBG && a.stamps && tid == 0 && (blockIdx.x & 63u) == 0) {
+            const long long now = clock64();
+            if (slot >= 0) atomicAdd(&a.stamps[slot], (unsigned long long)(now - t_prev));
+            t_prev = now;
+        }
+    };
+    stamp(-1);
+    const uint32_t q = a.q0 + blockIdx.x;
+    const uint32_t ndocs = (uint32_t)a.n_docs;  // single tile
+    const int rounds = (int)((ndocs + 4 * NT - 1) / (4 * NT));
+    uint4* const a4 = reinterpret_cast<uint4*>(acc);
+    accumulate_tile<TILE_DOCS, NT, U, false>(a, q, 0u, rounds, lds, ss, [](int) {}, tid);
+    stamp(0);
+
+    // the query's row of dense keys (the GEMM wrote it in ordinal order; docs past the corpus hold key 0 or, beyond
+    // the GEMM's last doc block, nothing): requested now, in flight during the sparse selection
+    uint32_t dk[E];
+    {
+        const uint4* row = reinterpret_cast<const uint4*>(h.dkeys + (uint64_t)blockIdx.x * h.ld);
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const uint4 x = r < rounds ? row[r * NT + tid] : make_uint4(0, 0, 0, 0);
+            dk[4 * r + 0] = x.x, dk[4 * r + 1] = x.y, dk[4 * r + 2] = x.z, dk[4 * r + 3] = x.w;
+        }
+    }
+    // ---- list membership: the depth best of each side (ties to the lower ordinal, like every list in this library).
+    // First-level bins: linear in the integer score / in the float VALUE of the dense score. The sparse scores stay in
+    // the LDS tile and are re-read per pass (accumulators of docs past the corpus are 0 by construction).
+    const HistResult hsp = hist_threshold<TILE_DOCS, NT>(
+        [&](int r) { return r < rounds ? a4[r * NT + tid] : make_uint4(0, 0, 0, 0); }, h.depth, hist, hcand, hs, tid,
+        [](uint32_t key, uint32_t lo) { return (float)(key - lo); });
+    stamp(1);
+#pragma unroll
+    for (int j = 0; j < E; ++j) {
+        const uint32_t local = 4u * ((uint32_t)(j / 4) * NT + tid) + (uint32_t)(j % 4);
+        if (local >= ndocs) dk[j] = 0;
+    }
+    const HistResult hde = hist_threshold<TILE_DOCS, NT>(
+        [&](int r) { return make_uint4(dk[4 * r], dk[4 * r + 1], dk[4 * r + 2], dk[4 * r + 3]); }, h.depth, hist, hcand, hs,
+        tid, [](uint32_t key, uint32_t lo) { return key_to_f32(key) - key_to_f32(lo); });
+    stamp(2);
+    // min / max of each run as get_run_dict records them (src/search.py:76-81): over the whole list
+    const bool has_s = hsp.n != 0, has_d = hde.n != 0;
+    const uint32_t smin_k = hsp.T > 1 ? (uint32_t)(hsp.T >> 13) : hsp.kmin, dmin_k = hde.T > 1 ? (uint32_t)(hde.T >> 13) : hde.kmin;
+    const float smin = has_s ? (float)smin_k : 0.f, smax = has_s ? (float)hsp.kmax : 0.f;
+    const float dmin = has_d ? key_to_f32(dmin_k) : 0.f, dmax = has_d ? key_to_f32(hde.kmax) : 0.f;
+    const float sden = fmaxf(smax - smin, 1e-9f), dden = fmaxf(dmax - dmin, 1e-9f);
+    const uint32_t self = h.self_ord ? (uint32_t)h.self_ord[q] : 0xFFFFFFFFu;
+    uint32_t sv[E];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const uint4 x = r < rounds ? a4[r * NT + tid] : make_uint4(0, 0, 0, 0);
+        sv[4 * r + 0] = x.x, sv[4 * r + 1] = x.y, sv[4 * r + 2] = x.z, sv[4 * r + 3] = x.w;
+    }
+    // (each thread rewrites only the accumulators it has just read; the selection scratch is dead)
+    if (tid < 64) ss.cnt[tid] = 0;
+    if (tid == 0) {
+        ss.n_cand = 0;
+        ss.tau0 = 1;
+        ss.smax = 0;
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        uint32_t fk[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int j = 4 * r + e;
+            const uint32_t local = 4u * ((uint32_t)r * NT + tid) + (uint32_t)e;
+            const uint64_t inv = (uint64_t)(TILE_DOCS - 1 - local);
+            const bool in_d = dk[j] != 0 && (((uint64_t)dk[j] << 13) | inv) >= hde.T;
+            const bool in_s = sv[j] != 0 && (((uint64_t)sv[j] << 13) | inv) >= hsp.T;
+            float f = 0.f;  // the reference adds the dense term first (runs = [dense, sparse], src/search.py:459)
+            if (in_d) f += h.w_dense * ((key_to_f32(dk[j]) - dmin) / dden);
+            if (in_s) f += h.w_sparse * (((float)sv[j] - smin) / sden);
+            fk[e] = ((in_d || in_s) && local != self) ? f32_to_key(f) : 0u;
+        }
+        if (r < rounds) a4[r * NT + tid] = make_uint4(fk[0], fk[1], fk[2], fk[3]);
+    }
+    __syncthreads();
+    stamp(3);
+    tile_select<TILE_DOCS, NT, CAND>(a4, cand, tmax, wmax, ss, rounds, 0ull, (int)h.k, res, [](int) {}, tid);
+    __syncthreads();
+    stamp(4);
+    if (tid < h.k) {
+        const uint64_t key = res[tid];
+        const uint64_t o = (uint64_t)q * h.k + tid;
+        h.out_ord[o] = key ? 0xFFFFFFFFu - (uint32_t)key : 0xFFFFFFFFu;
+        h.out_score[o] = key ? key_to_f32((uint32_t)(key >> 32)) : 0.f;
+    }
+    if (tid < 64) {
+        const uint32_t nh = (uint32_t)__popcll(__ballot(tid < h.k && res[tid] != 0));
+        if (tid == 0) h.out_n[q] = (int32_t)nh;
+    }
+}
+
+// rows of the passage matrix in ORDINAL order: P_ord[row2ord[r]] = P[r]
+__global__ __launch_bounds__(256) void permute_rows(const uint4* __restrict__ src, uint4* __restrict__ dst,
+                                                    const uint32_t* __restrict__ row2ord, uint32_t vecs_per_row) {
+    const uint32_t r = blockIdx.x;
+    const uint4* s = src + (uint64_t)r * vecs_per_row;
+    uint4* d = dst + (uint64_t)row2ord[r] * vecs_per_row;
+    for (uint32_t i = threadIdx.x; i < vecs_per_row; i += 256) d[i] = s[i];
+}
+
+}  // namespace msr
+
+// The fused path of msr_hybrid_search (single-tile indexes, k <= 64): per chunk of queries one GEMM launch on the
+// ordinal-permuted passage matrix, then hybrid_tiles; the chunk's score rows (<= 192 MB) stay in the Infinity Cache
+// between the two. ms = {fused scoring + selection + fusion kernel, dense GEMM, 0, 0}.
+static int hybrid_search_fused(msr_index* ix, msr_dense* dx, const int64_t* q_ptr, const int32_t* q_term, const int32_t* q_w,
+                               const uint16_t* q_fp16, int nq, int depth, int k, float alpha, uint32_t flags,
+                               const uint32_t* row2ord, const int32_t* self_ord, uint32_t* out_ord, float* out_score,
+                               int32_t* out_n, float ms[4]) {
+    DeviceIndex* d = ix->dev;
+    const IndexHeader* h = ix->host.h;
+    const uint64_t n = h->n_docs;
+    HIP_TRY(hipSetDevice(d->device));
+    // ---- passage rows in ordinal order (cached on the dense handle while the mapping is unchanged)
+    if (!dx->d_P_ord || dx->ord_map.size() != n || memcmp(dx->ord_map.data(), row2ord, (size_t)n * 4) != 0) {
+        std::vector<uint8_t> seen((size_t)n, 0);
+        for (uint64_t r = 0; r < n; ++r) {
+            if (row2ord[r] >= n || seen[row2ord[r]]) {
+                set_error("row2ord is not a permutation of the doc ordinals (row %llu -> %u)", (unsigned long long)r, row2ord[r]);
+                return MSR_E_INVAL;
+            }
+            seen[row2ord[r]] = 1;
+        }
+        uint32_t* d_map = nullptr;
+        const size_t bytes = (size_t)dx->n_pad * dx->h * 2;
+        if (!dx->d_P_ord && hipMalloc(&dx->d_P_ord, bytes) != hipSuccess) {
+            dx->d_P_ord = nullptr;
+            set_error("hipMalloc of %zu bytes for the ordinal-ordered passage matrix failed", bytes);
+            return MSR_E_NOMEM;
+        }
+        bool ok = hipMalloc(&d_map, std::max<size_t>((size_t)n, 1) * 4) == hipSuccess &&
+                  hipMemsetAsync(dx->d_P_ord, 0, bytes, d->stream) == hipSuccess &&
+                  hipMemcpyAsync(d_map, row2ord, (size_t)n * 4, hipMemcpyHostToDevice, d->stream) == hipSuccess;
+        if (ok && n) {
+            hipLaunchKernelGGL(permute_rows, dim3((uint32_t)n), dim3(256), 0, d->stream, reinterpret_cast<const uint4*>(dx->d_P),
+                               reinterpret_cast<uint4*>(dx->d_P_ord), d_map, dx->h / 8);
+            ok = hipGetLastError() == hipSuccess;
+        }
+        ok = ok && hipStreamSynchronize(d->stream) == hipSuccess;
+        if (d_map) (void)hipFree(d_map);
+        if (!ok) {
+            dx->ord_map.clear();
+            set_error("building the ordinal-ordered passage matrix failed: %s", hipGetErrorString(hipGetLastError()));
+            return MSR_E_HIP;
+        }
+        dx->ord_map.assign(row2ord, row2ord + n);
+    }
+    msr_batch* b = nullptr;
+    int rc = msr_batch_create(ix, q_ptr, q_term, q_w, nq, k, flags, &b);
+    if (rc != MSR_OK) return rc;
+    const uint32_t nt_threads = h->tile_docs == 4096 ? 256u : 512u;
+    const uint64_t ld = (n + 4 * nt_threads - 1) / (4 * nt_threads) * (4 * nt_threads);  // whole select rounds
+    const uint64_t n_cover = std::min<uint64_t>(dx->n_pad, (n + 255) / 256 * 256);
+    const uint32_t col_blocks = (uint32_t)(n_cover / 256);
+    // queries per chunk: two rounds of the chip's 256 CUs worth of 256 x 256 blocks, score rows <= 192 MB
+    uint32_t row_blocks = std::max<uint32_t>(1u, 512u / std::max(col_blocks, 1u));
+    row_blocks = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(row_blocks, (192ull << 20) / (ld * 4 * 256)));
+    const uint32_t qc = row_blocks * 256;
+    const uint32_t nq_pad = (uint32_t)((nq + 255) / 256 * 256);
+    _Float16* d_Q = nullptr;
+    uint32_t* d_S = nullptr;
+    uint32_t* d_ord = nullptr;
+    float* d_sf = nullptr;
+    int32_t *d_n = nullptr, *d_self = nullptr;
+    std::vector<hipEvent_t> ev;
+    unsigned long long* d_stamps = nullptr;  // diagnostic (MSR_DEBUG_HYBRID): phase clocks of wave 0
+    if (getenv("MSR_DEBUG_HYBRID") && hipMalloc(&d_stamps, 8 * sizeof(unsigned long long)) == hipSuccess)
+        (void)hipMemsetAsync(d_stamps, 0, 8 * sizeof(unsigned long long), d->stream);
+    const size_t perk = std::max<size_t>((size_t)nq * k, 1);
+    bool ok = hipMalloc(&d_Q, std::max<size_t>((size_t)nq_pad * dx->h * 2, 16)) == hipSuccess &&
+              hipMalloc(&d_S, (size_t)qc * ld * 4) == hipSuccess && hipMalloc(&d_ord, perk * 4) == hipSuccess &&
+              hipMalloc(&d_sf, perk * 4) == hipSuccess && hipMalloc(&d_n, std::max<size_t>(nq, 1) * 4) == hipSuccess;
+    if (ok && self_ord)
+        ok = hipMalloc(&d_self, std::max<size_t>(nq, 1) * 4) == hipSuccess &&
+             hipMemcpyAsync(d_self, self_ord, (size_t)nq * 4, hipMemcpyHostToDevice, d->stream) == hipSuccess;
+    if (ok && nq)
+        ok = hipMemsetAsync(d_Q + (size_t)nq * dx->h, 0, (size_t)(nq_pad - nq) * dx->h * 2, d->stream) == hipSuccess &&
+             hipMemcpyAsync(d_Q, q_fp16, (size_t)nq * dx->h * 2, hipMemcpyHostToDevice, d->stream) == hipSuccess;
+    if (!ok) {
+        set_error("device allocation or query upload failed in msr_hybrid_search (%u queries per chunk)", qc);
+        rc = MSR_E_NOMEM;
+    }
+    ScoreArgs sa;
+    sa.seg_ptr = d->d_seg_ptr;
+    sa.postings = d->d_postings;
+    sa.q_meta = reinterpret_cast<const uint4*>(b->d_qptr);
+    sa.q_term = b->d_qterm;
+    sa.q_w = b->d_qw;
+    sa.dense = d->d_dense;
+    sa.q_dense = b->d_qdense;
+    sa.n_pairs = d->n_pairs;
+    sa.part = nullptr;
+    sa.theta = nullptr;
+    sa.unsorted = 0;
+    sa.n_docs = n;
+    sa.vec_base = d->vec_base;
+    sa.n_terms = d->seg_terms;
+    sa.tile0 = 0;
+    sa.tl0 = 0;
+    sa.nq = (uint32_t)nq;
+    sa.k = (uint32_t)k;
+    sa.dump = nullptr;
+    sa.tpr = 1;
+    sa.dump_add = 0;
+    sa.dbg = 0;
+    sa.stamps = nullptr;
+    HybridArgs ha;
+    ha.dkeys = d_S;
+    ha.ld = ld;
+    ha.self_ord = d_self;
+    ha.depth = (uint32_t)depth;
+    ha.k = (uint32_t)k;
+    ha.w_dense = alpha;
+    ha.w_sparse = 1.0f - alpha;
+    ha.out_ord = d_ord;
+    ha.out_score = d_sf;
+    ha.out_n = d_n;
+    for (uint32_t q0 = 0; q0 < (uint32_t)nq && rc == MSR_OK; q0 += qc) {
+        const uint32_t qn = std::min<uint32_t>(qc, (uint32_t)nq - q0);
+        const uint32_t qn_pad = (qn + 255) / 256 * 256;
+        hipEvent_t e[3] = {nullptr, nullptr, nullptr};
+        for (auto& x : e) {
+            if (hipEventCreate(&x) != hipSuccess) rc = MSR_E_HIP;
+            ev.push_back(x);
+        }
+        if (rc != MSR_OK) {
+            set_error("hipEventCreate failed");
+            break;
+        }
+        (void)hipEventRecord(e[0], d->stream);
+        rc = launch_dense_gemm(dx, dx->d_P_ord, d_Q + (size_t)q0 * dx->h, d_S, qn, qn_pad, n_cover, ld, d->stream, true);
+        if (rc != MSR_OK) break;
+        (void)hipEventRecord(e[1], d->stream);
+        sa.q0 = q0;
+        sa.qn = qn;
+        sa.stamps = d_stamps;
+        if (d_stamps && h->tile_docs == 8192)
+            hipLaunchKernelGGL((hybrid_tiles<8192, 512, 4, 6, true>), dim3(qn), dim3(512), 0, d->stream, sa, ha);
+        else if (h->tile_docs == 4096)
+            hipLaunchKernelGGL((hybrid_tiles<4096, 256, 4, 5>), dim3(qn), dim3(256), 0, d->stream, sa, ha);
+        else
+            hipLaunchKernelGGL((hybrid_tiles<8192, 512, 4, 6>), dim3(qn), dim3(512), 0, d->stream, sa, ha);
+        if (hipGetLastError() != hipSuccess) {
+            set_error("hybrid_tiles launch failed: %s", hipGetErrorString(hipGetLastError()));
+            rc = MSR_E_HIP;
+            break;
+        }
+        (void)hipEventRecord(e[2], d->stream);
+    }
+    if (rc == MSR_OK && hipStreamSynchronize(d->stream) != hipSuccess) {
+        set_error("hybrid kernels failed: %s", hipGetErrorString(hipGetLastError()));
+        rc = MSR_E_HIP;
+    }
+    float t_gemm = 0, t_fused = 0;
+    if (rc == MSR_OK) {
+        for (size_t i = 0; i + 2 < ev.size(); i += 3) {
+            float a = 0, c = 0;
+            (void)hipEventElapsedTime(&a, ev[i], ev[i + 1]);
+            (void)hipEventElapsedTime(&c, ev[i + 1], ev[i + 2]);
+            t_gemm += a;
+            t_fused += c;
+        }
+        if (nq && (hipMemcpy(out_ord, d_ord, (size_t)nq * k * 4, hipMemcpyDeviceToHost) != hipSuccess ||
+                   hipMemcpy(out_score, d_sf, (size_t)nq * k * 4, hipMemcpyDeviceToHost) != hipSuccess ||
+                   hipMemcpy(out_n, d_n, (size_t)nq * 4, hipMemcpyDeviceToHost) != hipSuccess)) {
+            set_error("download failed in msr_hybrid_search");
+            rc = MSR_E_HIP;
+        }
+    }
+    if (ms) {
+        ms[0] = t_fused;
+        ms[1] = t_gemm;
+        ms[2] = 0.f;
+        ms[3] = 0.f;
+    }
+    if (d_stamps) {
+        unsigned long long st[8] = {0};
+        (void)hipMemcpy(st, d_stamps, sizeof(st), hipMemcpyDeviceToHost);
+        fprintf(stderr, "[msr] hybrid_tiles wave-0 clocks: accumulate %llu, sparse select %llu, dense select %llu, fuse %llu, "
+                        "top-k %llu (sums over 1 workgroup in 64)\n", st[0], st[1], st[2], st[3], st[4]);
+        (void)hipFree(d_stamps);
+    }
+    for (hipEvent_t x : ev)
+        if (x) (void)hipEventDestroy(x);
+    void* ptrs[] = {d_Q, d_S, d_ord, d_sf, d_n, d_self};
+    for (void* p2 : ptrs)
+        if (p2) (void)hipFree(p2);
+    batch_free(b);
+    return rc;
+}
+
 extern "C" {
 
 int msr_hybrid_search(msr_index* ix, msr_dense* dx, const int64_t* q_ptr, const int32_t* q_term, const int32_t* q_w,
@@ -547,6 +912,11 @@ int msr_hybrid_search(msr_index* ix, msr_dense* dx, const int64_t* q_ptr, const 
     }
     DeviceIndex* d = ix->dev;
     const IndexHeader* h = ix->host.h;
+    static const bool no_fused = getenv("MSR_NO_FUSED_HYBRID") != nullptr;  // diagnostic: force the list-based path
+    if (!no_fused && h->n_tiles == 1 && ix->shard_ntiles == 1 && ix->term_nshards == 0 && k <= 64 && dx->h % 8 == 0 &&
+        (h->tile_docs == 4096 || h->tile_docs == 8192))
+        return hybrid_search_fused(ix, dx, q_ptr, q_term, q_w, q_fp16, nq, depth, k, alpha, flags, row2ord, self_ord,
+                                   out_ord, out_score, out_n, ms);
     msr_batch* b = nullptr;
     int rc = msr_batch_create(ix, q_ptr, q_term, q_w, nq, depth, flags, &b);
     if (rc != MSR_OK) return rc;

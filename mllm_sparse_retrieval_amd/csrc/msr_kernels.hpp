@@ -19,7 +19,7 @@
 // merge_lists    one workgroup per query: exact top-k of best-first lists (per tile or per shard).
 #pragma once
 
-#include "msr_select.hpp"
+#include "msr_accumulate.hpp"
 
 namespace msr {
 
@@ -27,30 +27,18 @@ namespace msr {
 // <docs per tile, threads, 1-KiB chunk loads per register bank, min waves per SIMD, candidate-key capacity (>= k), diag>
 template <int TILE_DOCS, int NT, int U, int MIN_WAVES, int CAND, bool DBG, int MODE = 0>
 __global__ __launch_bounds__(NT, MIN_WAVES) void score_tiles(const ScoreArgs a) {
-    constexpr int NW = NT / 64;
-    static_assert(TILE_DOCS % (4 * NT) == 0, "tile must be a multiple of 4*NT");
-    static_assert(NT >= kQtBlock, "the staging scan uses the first 256 threads");
     using L = TileLds<TILE_DOCS, NT, CAND>;
 
     __shared__ __attribute__((aligned(16))) uint8_t lds[L::kTotal];
     uint32_t* const acc = reinterpret_cast<uint32_t*>(lds);
     uint8_t* const un = lds + L::kAcc;
-    // streaming-phase view of the union
-    uint32_t* const seg_start = reinterpret_cast<uint32_t*>(un);
-    uint32_t* const seg_len = seg_start + kQtBlock;
-    uint32_t* const seg_w = seg_len + kQtBlock;
-    uint32_t* const pref = seg_w + kQtBlock;
-    uint32_t* const wsum = pref + kQtBlock + 4;
-    // select-phase view of the union
+    // select-phase view of the union (the accumulation phase's staging arrays live in the same bytes)
     uint64_t* const cand = reinterpret_cast<uint64_t*>(un);
     uint32_t* const tmax = reinterpret_cast<uint32_t*>(un + L::kUnion);
     uint32_t* const wmax = tmax + NT;
     SelectScratch& ss = *reinterpret_cast<SelectScratch*>(un + L::kUnion + L::kTmax);
 
     const uint32_t tid = threadIdx.x;
-    const uint32_t lane = tid & 63;
-    const uint32_t lane16 = lane * 16u;         // byte offset of the lane's vec inside a chunk
-    const uint32_t wave = rfl(tid >> 6);        // provably wave-uniform for the compiler
     // diagnostic build only: wave 0 stamps s_memtime at phase boundaries and adds the deltas to a side buffer
     long long t_prev = 0;
     auto stamp = [&](int slot) {
@@ -73,233 +61,9 @@ __global__ __launch_bounds__(NT, MIN_WAVES) void score_tiles(const ScoreArgs a) 
     const int rounds = (int)((ndocs_tile + 4 * NT - 1) / (4 * NT));
     uint4* const a4 = reinterpret_cast<uint4*>(acc);
 
-    const uint4 meta = a.q_meta[q];  // one scalar load: term range + which dense-head pairs the query holds
     // staged search: the query's k-th best key over the tiles of an earlier launch (0: fewer than k hits so far)
     const uint64_t theta = (MODE == 0 && a.theta) ? a.theta[(uint64_t)q * a.k + (a.k - 1)] : 0ull;
-    const uint32_t qb = meta.x, qe = meta.y;
-    const uint32_t* seg_row = a.seg_ptr + (uint64_t)tile_l * (a.n_terms + 1);
-    // Postings and dense rows are read with buffer loads: (tile base + size in SGPRs) + (32-bit byte offset per
-    // lane). A tile's segments span less than 4 GiB (checked when the index is attached); there is no 64-bit address
-    // arithmetic per chunk (the scalar ALU is shared by the CU's 32 waves), no zero-extended offset pairs in VGPRs,
-    // and a read past the tile's postings returns 0 instead of faulting.
-    const uint32_t tile_first = seg_row[0];
-    const char* const post_base = reinterpret_cast<const char*>(a.postings) + (uint64_t)(tile_first - a.vec_base) * 16u;
-
-    // ---- first round's (term -> segment) lookups: two dependent global loads. The first (terms, weights) goes out
-    // now; the second (segment pointers) needs the terms, so it is issued AFTER the first dense rows have been
-    // requested — otherwise the wait for the terms would hold the rows back by a round trip.
-    uint32_t pre_t = 0, pre_w = 0, pre_s0 = 0, pre_s1 = 0;
-    const bool has_lk = tid < min((uint32_t)kQtBlock, qe - qb);
-    if (has_lk) {
-        pre_t = a.q_term[qb + tid];
-        pre_w = a.q_w[qb + tid];
-    }
-    auto lookup2 = [&]() {
-        if (has_lk) {
-            pre_s0 = seg_row[pre_t];
-            pre_s1 = seg_row[pre_t + 1];
-        }
-    };
-
-    // ---- initialise the accumulators: zero, or — when the query holds dense-head terms — their whole contribution.
-    // Thread `tid` owns vecs r*NT + tid (4 consecutive docs each); the dense head is doc-major, one dword per doc and
-    // term pair, so the owner scores two postings per v_dot2_u32_u16 and stores the sums with a plain ds_write_b128:
-    // no atomics, and no separate zeroing pass. Term pairs the query does not hold are skipped (wave-uniform bit
-    // mask); the rows of the next pair are in flight while the current pair is accumulated (two register banks).
-    {
-        typedef unsigned short us2 __attribute__((ext_vector_type(2)));
-        constexpr int RG = 4;  // rounds per register group
-        const uint32_t qv = lane < a.n_pairs ? a.q_dense[(uint64_t)q * a.n_pairs + lane] : 0u;
-        // (the mask comes with the scalar load above, so the first rows are requested without waiting for qv)
-        const uint32_t pmask = (DBG && (a.dbg & 16u)) ? 0u : meta.z;
-        const __amdgpu_buffer_rsrc_t rs_dense =
-            make_rsrc(reinterpret_cast<const char*>(a.dense) + (uint64_t)tile_l * a.n_pairs * (TILE_DOCS * 4u),
-                      a.n_pairs * (uint32_t)(TILE_DOCS * 4));
-        for (int r0 = 0; r0 < rounds; r0 += RG) {
-            uint4 sacc[RG];
-#pragma unroll
-            for (int i = 0; i < RG; ++i) sacc[i] = make_uint4(0, 0, 0, 0);
-            if (pmask) {
-                uint32_t voff[RG];  // byte offset of this thread's vec in a pair's row, per round of the group
-#pragma unroll
-                for (int i = 0; i < RG; ++i)  // rows past `rounds` re-read the last real round (result unused)
-                    voff[i] = ((uint32_t)min(r0 + i, rounds - 1) * NT + tid) * 16u;
-                auto load_rows = [&](uint4 (&x)[RG], uint32_t p) {
-#pragma unroll
-                    for (int i = 0; i < RG; ++i) x[i] = buf_load16(rs_dense, voff[i], p * (uint32_t)(TILE_DOCS * 4));
-                };
-                auto add_rows = [&](const uint4 (&x)[RG], uint32_t qp) {
-                    const us2 qq = __builtin_bit_cast(us2, qp);
-#pragma unroll
-                    for (int i = 0; i < RG; ++i) {
-                        sacc[i].x = __builtin_amdgcn_udot2(__builtin_bit_cast(us2, x[i].x), qq, sacc[i].x, false);
-                        sacc[i].y = __builtin_amdgcn_udot2(__builtin_bit_cast(us2, x[i].y), qq, sacc[i].y, false);
-                        sacc[i].z = __builtin_amdgcn_udot2(__builtin_bit_cast(us2, x[i].z), qq, sacc[i].z, false);
-                        sacc[i].w = __builtin_amdgcn_udot2(__builtin_bit_cast(us2, x[i].w), qq, sacc[i].w, false);
-                    }
-                };
-                uint32_t m = pmask;
-                uint4 xa[RG], xb[RG];
-                uint32_t pa = (uint32_t)__builtin_ctz(m), pb = 0;
-                m &= m - 1;
-                load_rows(xa, pa);
-                if (r0 == 0) lookup2();
-                for (;;) {
-                    const bool more_b = m != 0;
-                    if (more_b) {
-                        pb = (uint32_t)__builtin_ctz(m);
-                        m &= m - 1;
-                        load_rows(xb, pb);
-                    }
-                    add_rows(xa, rdl(qv, pa));
-                    if (!more_b) break;
-                    const bool more_a = m != 0;
-                    if (more_a) {
-                        pa = (uint32_t)__builtin_ctz(m);
-                        m &= m - 1;
-                        load_rows(xa, pa);
-                    }
-                    add_rows(xb, rdl(qv, pb));
-                    if (!more_a) break;
-                }
-            }
-#pragma unroll
-            for (int i = 0; i < RG; ++i)
-                if (r0 + i < rounds) a4[(r0 + i) * NT + tid] = sacc[i];
-        }
-        if (!pmask) lookup2();  // (no dense rows were requested)
-    }
-    if (tid < 64) ss.cnt[tid] = 0;
-    if (tid == 0) {
-        ss.n_cand = 0;
-        ss.tau0 = 1;
-        ss.smax = 0;
-    }
-
-    for (uint32_t base = qb; base < qe; base += kQtBlock) {
-        const uint32_t cnt = min((uint32_t)kQtBlock, qe - base);
-        if (base != qb) __syncthreads();  // the previous round's readers of seg_* / pref are done (the accumulator
-                                          // init is ordered before the atomics by the two barriers below)
-        stamp(0);  // zeroing (+ q_ptr fetch)
-        // ---- stage the round's segments and an exclusive prefix sum of their chunk counts
-        uint32_t nch = 0;
-        if (tid < kQtBlock) {
-            if (tid < cnt) {
-                uint32_t s0 = pre_s0, s1 = pre_s1, w = pre_w;
-                if (base != qb) {
-                    const uint32_t t = a.q_term[base + tid];
-                    s0 = seg_row[t];
-                    s1 = seg_row[t + 1];
-                    w = a.q_w[base + tid];
-                }
-                seg_start[tid] = s0 - tile_first;  // vec index inside the tile
-                seg_len[tid] = s1 - s0;
-                seg_w[tid] = w;
-                nch = (s1 - s0 + kChunkVecs - 1) / kChunkVecs;
-            }
-            const uint32_t inc = wave_inclusive_scan_u32(nch);
-            if (lane == 63) wsum[wave] = inc;
-            nch = inc - nch;  // exclusive within the wave
-        }
-        __syncthreads();
-        if (tid < kQtBlock) {
-            // (written without a loop: hipcc vectorises `for (w < wave) off += wsum[w]` into a 32-wide LDS sweep)
-            const uint32_t w0 = wsum[0], w1 = wsum[1], w2 = wsum[2], w3 = wsum[3];
-            const uint32_t off = (wave > 0 ? w0 : 0u) + (wave > 1 ? w1 : 0u) + (wave > 2 ? w2 : 0u);
-            pref[tid] = nch + off;
-            if (tid == kQtBlock - 1) pref[kQtBlock] = w0 + w1 + w2 + w3;
-        }
-        __syncthreads();
-        // ---- the round's chunks are dealt round-robin to the waves (chunk c -> wave c % NW), which spreads the
-        // dense head terms and the one-chunk tail terms evenly. The (term, offset) of a wave's next 64 chunks is
-        // resolved lane-parallel (one binary search per lane), then broadcast chunk by chunk with v_readlane, so
-        // the inner loop is scalar control + one 16-byte load and four LDS atomics per lane.
-        stamp(1);  // staging: segment table + chunk-count scan
-        if (DBG && (a.dbg & 64u)) break;  // ablation: stop after staging
-        const uint32_t total = rfl(pref[kQtBlock]);
-        const uint32_t c_end = total > wave ? (total - wave + NW - 1) / NW : 0u;  // chunks of this wave
-        for (uint32_t cb = 0; cb < c_end; cb += 64) {
-            const uint32_t my_i = cb + lane;
-            // Branch-free lower-bound search, the same (wave-uniform) number of steps in every lane: largest lo with
-            // pref[lo] <= my_c. Entries past `cnt` hold the round's total (> every chunk index), and lanes past c_end
-            // search for a chunk that does not exist — their reads stay inside pref[] and their m_n is forced to 0.
-            const uint32_t my_c = wave + my_i * NW;
-            uint32_t lo = 0;
-            // first step = largest power of two below cnt (lo + step >= cnt can never be taken); none when cnt == 1
-            for (uint32_t step = cnt > 1 ? 1u << (31 - __clz((int)(cnt - 1))) : 0u; step > 0; step >>= 1) {
-                const uint32_t mid = lo + step;
-                lo = pref[mid] <= my_c ? mid : lo;
-            }
-            // (byte units: the loads below take them as scalar offset / clamp without further arithmetic)
-            const uint32_t voff = (my_c - pref[lo]) * kChunkVecs;
-            const uint32_t m_b16 = my_i < c_end ? (seg_start[lo] + voff) << 4 : 0u;  // idle slots: the tile's first vec
-            const uint32_t m_n16 = my_i < c_end ? min((uint32_t)kChunkVecs, seg_len[lo] - voff) << 4 : 0u;
-            const uint32_t m_w = seg_w[lo];
-            stamp(7);  // lane-parallel chunk resolution (binary search)
-            if (DBG && (a.dbg & 256u)) break;  // ablation: stop after the first chunk resolution
-            const uint32_t nchunk = min(64u, c_end - cb);
-            // Software pipeline, two register banks of U chunks: the next bank's 1-KiB loads are in flight while
-            // the current bank's LDS atomics issue. Loads are unconditional (lanes past a chunk's end, and chunk
-            // slots past nchunk, re-read the chunk's / the shard's first vec) so that the compiler can count them
-            // with s_waitcnt vmcnt(N) instead of draining to vmcnt(0); only the atomics are predicated.
-            // (a chunk's byte length stays in an SGPR from its load to its atomics: one v_readlane less per chunk)
-            auto load_bank = [&](uint4 (&v)[U], uint32_t (&sn16)[U], uint32_t u0) {
-#pragma unroll
-                for (int u = 0; u < U; ++u) {
-                    const uint32_t idx = u0 + u;  // < 64: u0 + U <= nchunk rounded up to a multiple of U
-                    const uint32_t b16 = rdl(m_b16, idx);
-                    const uint32_t n16 = rdl(m_n16, idx);
-                    sn16[u] = n16;
-                    if (DBG && (a.dbg & 2u)) {  // ablation: no global loads, synthetic postings
-                        const uint32_t hsh = ((cb + idx) * 64u + lane) * 2654435761u;
-                        v[u] = make_uint4((1u << 16) | (hsh >> 17), (1u << 16) | ((hsh * 31u) >> 17),
-                                          (1u << 16) | ((hsh * 131u) >> 17), (1u << 16) | ((hsh * 1031u) >> 17));
-                    } else {
-                        // The chunk's END offset goes into the resource's size word: the buffer range check compares
-                        // scalar + lane offset with it, so lanes past the chunk's end — and every lane of an idle
-                        // slot — get zeros without a memory request, with no clamp instruction; the lane offset is
-                        // the loop-invariant lane16.
-                        v[u] = buf_load16(make_rsrc(post_base, b16 + n16), lane16, b16);
-                    }
-                }
-            };
-            auto add_bank = [&](const uint4 (&v)[U], const uint32_t (&sn16)[U], uint32_t u0) {
-#pragma unroll
-                for (int u = 0; u < U; ++u) {
-                    const uint32_t idx = u0 + u;
-                    const uint32_t n16 = sn16[u];  // 0 in the slots past nchunk
-                    const uint32_t w = rdl(m_w, idx);
-                    // lanes past the chunk's last vec must not touch LDS (64 lanes adding to one accumulator would
-                    // serialise); padding INSIDE a vec has weight 0 and a lane-distinct ordinal
-                    if (lane16 < n16) {
-                        const uint32_t p[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
-                        if (DBG && (a.dbg & 1u)) {  // ablation: no LDS atomics (keep the loads alive)
-                            if ((p[0] ^ p[1] ^ p[2] ^ p[3]) == 0xDEADBEEFu) atomicAdd(&acc[0], 1u);
-                        } else {
-#pragma unroll
-                            for (int e = 0; e < 4; ++e)
-                                atomicAdd(&acc[DBG ? (p[e] & 0xFFFFu) % TILE_DOCS : (p[e] & 0xFFFFu)],
-                                          __umul24(p[e] >> 16, w));
-                        }
-                    }
-                }
-            };
-            uint4 va[U], vb[U];
-            uint32_t na[U], nb[U];
-            load_bank(va, na, 0);
-            for (uint32_t u0 = 0; u0 < nchunk; u0 += 2 * U) {
-                const bool more = u0 + U < nchunk;  // wave-uniform
-                if (more) load_bank(vb, nb, u0 + U);
-                add_bank(va, na, u0);
-                if (more) {
-                    if (u0 + 2 * U < nchunk) load_bank(va, na, u0 + 2 * U);
-                    add_bank(vb, nb, u0 + U);
-                }
-            }
-        }
-    }
-    stamp(2);  // wave 0's own streaming
-    __syncthreads();  // accumulation complete; the staging view of the union is dead from here on
+    accumulate_tile<TILE_DOCS, NT, U, DBG>(a, q, tile_l, rounds, lds, ss, stamp, tid);
     stamp(3);  // waiting for the slowest wave
 
     // =============================================================== exact top-k of this tile

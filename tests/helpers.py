@@ -102,3 +102,44 @@ def assert_same_results(got, want, k):
     assert np.abs(g_f32.astype(np.float64)[mask] - w_sc.astype(np.float64)[mask]
                   ).max(initial=0) <= np.where(w_sc.max(initial=0) < 2**24, 1e-5, np.inf)
     assert (g_u32[~mask] == 0).all()
+
+
+def dense_oracle(q, p, k):
+    """numpy f32 inner products of the fp16-ROUNDED inputs (the storage precision of the reference's GPU faiss,
+    src/search.py:257), ranked by (-score, row). Tolerance on scores: 1e-5 (f32 accumulation order)."""
+    s = q.astype(np.float16).astype(np.float32) @ p.astype(np.float16).astype(np.float32).T
+    order = np.lexsort((np.broadcast_to(np.arange(s.shape[1]), s.shape), -s), axis=1)[:, :k]
+    return np.take_along_axis(s, order, axis=1), order
+
+
+def oracle_hybrid(docs, n_terms, ids, qp, qt, qw, q, p, depth, alpha, sample, remove_query=False, qids=None):
+    """The reference's hybrid pipeline driven by the oracles for the queries in `sample`: C oracle sparse top-depth +
+    numpy dense top-depth -> oracle.get_run_dict -> oracle.fuse (pinned to src/hybrid.py:32-53).
+    -> ({qid: {doc: fused}}, qids of the sample)"""
+    from oracle import oracle
+
+    oix, order = taat_oracle(docs, n_terms, ids)
+    sorted_ids = [ids[r] for r in order]
+    sample = np.asarray(sample)
+    sel = np.concatenate([np.arange(qp[i], qp[i + 1]) for i in sample]) if len(sample) else np.zeros(0, np.int64)
+    sp = np.concatenate([[0], np.cumsum(qp[sample + 1] - qp[sample])]).astype(np.int64)
+    wo, wsc, wn = oix.search(sp, qt[sel], qw[sel], depth, threads=16)
+    sq = [str(int(i)) for i in sample] if qids is None else [qids[int(i)] for i in sample]
+    o_sparse = oracle.get_run_dict(sq, [[float(np.float32(x)) for x in wsc[j, :wn[j]]] for j in range(len(sample))],
+                                   [[sorted_ids[int(d)] for d in wo[j, :wn[j]]] for j in range(len(sample))], remove_query)
+    dsc, didx = dense_oracle(q[sample], p, min(depth, p.shape[0]))
+    o_dense = oracle.get_run_dict(sq, dsc, np.array([[ids[j] for j in row] for row in didx]), remove_query)
+    return oracle.fuse([o_dense, o_sparse], [alpha, 1 - alpha]), sq
+
+
+def assert_hybrid_matches(want, sq, sample, ords, fs, cnt, docid_of, k, tol=1e-5, tie=2e-6):
+    worst = 0.0
+    for j, i in enumerate(sample):
+        ranked = sorted(want[sq[j]].items(), key=lambda kv: (-float(kv[1]), kv[0].encode()))[:k]
+        assert cnt[i] == len(ranked), (sq[j], cnt[i], len(ranked))
+        for r, (doc, score) in enumerate(ranked):
+            worst = max(worst, abs(float(fs[i, r]) - float(score)))
+            g = docid_of(int(ords[i, r]))
+            if g != doc:  # only a near-tie in the fused score may swap neighbours
+                assert g in want[sq[j]] and abs(float(want[sq[j]][g]) - float(score)) <= tie, (sq[j], r, g, doc)
+    assert worst <= tol, worst

@@ -461,12 +461,7 @@ def _unit_rows(rng, n, h):
     return x / np.linalg.norm(x, axis=1, keepdims=True)
 
 
-def _dense_oracle(q, p, k):
-    """numpy f32 inner products of the fp16-ROUNDED inputs (the storage precision of the reference's GPU faiss,
-    src/search.py:257), ranked by (-score, row). Tolerance on scores: 1e-5 (f32 accumulation order)."""
-    s = q.astype(np.float16).astype(np.float32) @ p.astype(np.float16).astype(np.float32).T
-    order = np.lexsort((np.broadcast_to(np.arange(s.shape[1]), s.shape), -s), axis=1)[:, :k]
-    return np.take_along_axis(s, order, axis=1), order
+_dense_oracle = helpers.dense_oracle
 
 
 # (the third-last case fills >= 256 blocks of 256 x 256: the LDS-DMA GEMM kernel; the others take the 128 x 128 one)
@@ -566,7 +561,8 @@ def test_gpu_fusion_matches_host_fuse(m, tmp_path, n, alpha, remove):
     d_scores, d_ids = search_queries(dr, q, ids, SimpleNamespace(batch_size=64, depth=depth, quiet=True))
     dense_run = get_run_dict(qids, d_scores, d_ids, remove)
     want = fuse([dense_run, sparse_run], [alpha, 1 - alpha])
-    assert ms["fusion"] > 0
+    assert ms["sparse"] > 0 and ms["dense_gemm"] > 0  # (3 000 docs = one tile: fused kernel; 9 000 = list-based path)
+    assert (ms["fusion"] > 0) == (n > 8192)
     for i, qid in enumerate(qids):
         ranked = sorted(want[qid].items(), key=lambda kv: (-float(kv[1]), kv[0].encode()))[:k]
         assert cnt[i] == len(ranked)
@@ -636,6 +632,84 @@ def test_c5_real_shape_dense_and_hybrid_vs_oracle_pipeline(m, tmp_path):
             if g != doc:  # only a near-tie in the fused score may swap neighbours
                 assert g in want[qid] and abs(float(want[qid][g]) - float(score)) <= 2e-6, (qid, r, g, doc)
     assert worst <= 1e-5
+
+
+@pytest.mark.parametrize("n,tile,depth,k,alpha,remove", [(3000, 0, 300, 10, 0.5, False), (3000, 0, 100, 10, 0.3, True),
+                                                       (8000, 0, 1000, 64, 0.7, False), (700, 4096, 1024, 10, 0.5, False),
+                                                       (5000, 0, 5000 // 5, 1, 0.0, False), (4097, 8192, 50, 5, 1.0, True)])
+def test_fused_hybrid_tile_vs_oracle_pipeline(m, tmp_path, n, tile, depth, k, alpha, remove):
+    """The fused single-tile hybrid kernel (scores + both depth-selections + fusion + top-k in one workgroup per query)
+    against the oracle pipeline, every query: list sizes above and below the corpus size, alpha at both ends (one run
+    contributes nothing but still defines membership of the union), remove_query, k = 1 and k = 64."""
+    from mllm_sparse_retrieval_amd.dense import DenseIndex, hybrid_search, row_to_ordinal
+
+    nq, n_terms, h = 150, 2000, 64
+    docs, (qp, qt, qw) = helpers.synth(n, 48, nq, 30, n_terms, seed=n + depth)
+    ids = [str(i) for i in range(n)]
+    path = m.build_index_from_csr(str(tmp_path / "f.idx"), *docs, n_terms, doc_ids=ids, tile_docs=tile)
+    rng = np.random.default_rng(n)
+    p, q = _unit_rows(rng, n, h), _unit_rows(rng, nq, h)
+    qids = [str(i) for i in range(nq)]                        # query ids collide with doc ids -> remove_query matters
+    with m.SparseIndex(path, device=0) as ix:
+        assert ix.n_tiles == 1
+        dix = DenseIndex(p)
+        r2o = row_to_ordinal(ix, ids)
+        self_ord = np.array([int(r2o[int(x)]) for x in qids], dtype=np.int32) if remove else None
+        ords, fs, cnt, ms = hybrid_search(ix, dix, qp, qt, qw, q, min(depth, 1024), k, alpha, r2o, self_ord)
+        assert ms["dense_select"] == 0 and ms["fusion"] == 0 and ms["sparse"] > 0   # the fused kernel ran
+        docid_of = ix.docid
+        sample = np.arange(nq)
+        want, sq = helpers.oracle_hybrid(docs, n_terms, ids, qp, qt, qw, q, p, min(depth, 1024), alpha, sample, remove, qids)
+        helpers.assert_hybrid_matches(want, sq, sample, ords, fs, cnt, docid_of, k)
+        if remove:
+            assert all(qids[i] not in [docid_of(int(o)) for o in ords[i, :cnt[i]]] for i in range(nq))
+        dix.close()
+
+
+def test_fused_hybrid_mass_ties(m, tmp_path):
+    """Every doc holds the same term with the same weight: all sparse scores tie, so the sparse top-`depth` list is the
+    `depth` LOWEST ordinals (doc-id string order) — the selection's histogram collapses into one bin and has to split
+    it by ordinal. Dense vectors repeat in blocks of 8, so dense scores tie exactly as well."""
+    from mllm_sparse_retrieval_amd.dense import DenseIndex, hybrid_search, row_to_ordinal
+
+    n, V, h, nq, depth, k = 6000, 8, 32, 40, 700, 10
+    dp = np.arange(n + 1, dtype=np.uint64)
+    dt = np.full(n, 3, dtype=np.uint32)
+    dw = np.full(n, 7, dtype=np.uint32)
+    dt[::2] = 4
+    ids = [str(i) for i in range(n)]
+    path = m.build_index_from_csr(str(tmp_path / "t.idx"), dp, dt, dw, V, doc_ids=ids)
+    qp = np.arange(nq + 1, dtype=np.int64)
+    qt = np.where(np.arange(nq) % 2 == 0, 3, 4).astype(np.int32)
+    qw = np.full(nq, 2, dtype=np.int32)
+    rng = np.random.default_rng(1)
+    base = _unit_rows(rng, n // 8, h)
+    p = np.repeat(base, 8, axis=0)
+    q = _unit_rows(rng, nq, h)
+    with m.SparseIndex(path, device=0) as ix:
+        dix = DenseIndex(p)
+        r2o = row_to_ordinal(ix, ids)
+        ords, fs, cnt, ms = hybrid_search(ix, dix, qp, qt, qw, q, depth, k, 0.5, r2o)
+        # sparse side: the 700 lowest ordinals among the 3 000 docs that hold the query's term, all at normalised score
+        # (s - min) / max(max - min, 1e-9) = 0 -> the fused score is the dense half alone, and a doc outside BOTH lists
+        # cannot appear. Dense ties (8 equal rows) are cut by ordinal in the fused path: membership of the dense list
+        # is checked through the score alone.
+        sfull = q.astype(np.float16).astype(np.float32) @ p.astype(np.float16).astype(np.float32).T
+        term_docs = {3: np.flatnonzero(dt == 3), 4: np.flatnonzero(dt == 4)}
+        for i in range(nq):
+            rows_with_term = term_docs[int(qt[i])]
+            by_ord = sorted(rows_with_term, key=lambda r: r2o[r])[:depth]          # sparse list = lowest ordinals
+            kth = np.sort(sfull[i])[::-1][depth - 1]
+            dmin, dmax = kth, sfull[i].max()
+            assert cnt[i] == k
+            for j in range(k):
+                row = int(np.flatnonzero(r2o == ords[i, j])[0])
+                in_dense = sfull[i, row] >= kth - 1e-7
+                assert in_dense or row in by_ord
+                want = 0.5 * (sfull[i, row] - dmin) / max(dmax - dmin, 1e-9) if in_dense else 0.0
+                assert abs(float(fs[i, j]) - want) <= 1e-5
+            assert (np.diff(fs[i, :k]) <= 0).all()
+        dix.close()
 
 
 def test_randomised_configurations(m, tmp_path):
