@@ -565,14 +565,60 @@ struct HybridArgs {
     int32_t* out_n;           // [nq]
 };
 
+// The rare paths of hybrid_tiles, kept OUT OF LINE: inlined, the general selections' live ranges cost the common path
+// ~100 spilled VGPRs (measured: 316 -> 20 bytes of scratch per lane). `keys` is the thread-interleaved tile of u32 keys
+// (LDS accumulators, or the query's row of dense keys in global memory); dense keys are canonicalised like the fast
+// path's floats (-0 = +0) and docs past the corpus masked out.
+template <int TILE_DOCS, int NT>
+__device__ __attribute__((noinline)) uint64_t threshold_general(const uint32_t* keys, int rounds, uint32_t ndocs, uint32_t k,
+                                                                bool dense, uint32_t* hist, uint64_t* cand, HistScratch* hs,
+                                                                uint32_t tid) {
+    const HistResult g = hist_threshold<TILE_DOCS, NT>(
+        [&](int r) {
+            uint4 x = r < rounds ? reinterpret_cast<const uint4*>(keys)[r * NT + tid] : make_uint4(0, 0, 0, 0);
+            if (dense) {
+                uint32_t k4[4] = {x.x, x.y, x.z, x.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const uint32_t local = 4u * ((uint32_t)r * NT + tid) + (uint32_t)e;
+                    k4[e] = (r < rounds && local < ndocs) ? f32_to_key(key_to_f32(k4[e]) + 0.0f) : 0u;
+                }
+                x = make_uint4(k4[0], k4[1], k4[2], k4[3]);
+            }
+            return x;
+        },
+        k, hist, cand, *hs, tid,
+        [dense](uint32_t key, uint32_t lo) { return dense ? key_to_f32(key) - key_to_f32(lo) : (float)(key - lo); });
+    return g.T > 1 ? g.T : ((uint64_t)g.kmin << 13);  // (everything present belongs: the smallest key, any doc)
+}
+
+template <int TILE_DOCS, int NT, int CAND>
+__device__ __attribute__((noinline)) void tile_select_general(const uint4* a4, uint64_t* cand, uint32_t* tmax, uint32_t* wmax,
+                                                              SelectScratch* ss, int rounds, int k, uint64_t* out,
+                                                              uint32_t tid) {
+    tile_select<TILE_DOCS, NT, CAND>(a4, cand, tmax, wmax, *ss, rounds, 0ull, k, out, [](int) {}, tid);
+}
+
+// scratch of the dual selection (separate from the tile's LDS carve, which accumulate_tile and tile_select own)
+struct DualScratch {
+    uint32_t red[8];      // smax, ~smin', scount, key(dmax), ~key(dmin), member count, -, -   (LDS atomics, one per wave)
+    uint32_t wtot[2][8];  // per-side wave totals of the bin scan
+    uint32_t bin[2], above[2], cnt[2], ncand[2];
+    uint64_t T[2];        // threshold composites  key << 13 | (TILE_DOCS - 1 - local)
+    uint32_t fbin, fabove, fcnt, fn;  // final top-k: bin of the k-th best fused score, members above it, in it, collected
+};
+
 template <int TILE_DOCS, int NT, int U, int MIN_WAVES, bool DBG = false>
 __global__ __launch_bounds__(NT, MIN_WAVES) void hybrid_tiles(const ScoreArgs a, const HybridArgs h) {
     constexpr int CAND = 1024;
-    constexpr int E = TILE_DOCS / NT, R = E / 4;
+    constexpr int E = TILE_DOCS / NT, R = E / 4, NW = NT / 64, HW = NW / 2;
+    constexpr int BPT = kHistBins / (HW * 64);  // bins per scanning thread (half of the workgroup scans each side)
+    static_assert(BPT == 4 || BPT == 8, "the scan reads its bins as one or two 16-byte vectors");
     using L = TileLds<TILE_DOCS, NT, CAND>;
-    static_assert(L::kUnion >= kHistBins * 4 + kHistCand * 8, "histogram + candidates share the select union");
-    static_assert(L::kTmax >= (int)sizeof(HistScratch), "the selection scratch lives in the maxima region");
+    static_assert(L::kUnion >= 2 * kHistBins * 4 && L::kUnion >= 2 * kHistCand * 8, "two histograms / candidate lists");
+    static_assert(L::kTmax >= (int)sizeof(HistScratch), "the fallback selection's scratch lives in the maxima region");
     __shared__ __attribute__((aligned(16))) uint8_t lds[L::kTotal];
+    __shared__ DualScratch ds;
     __shared__ uint64_t res[64];
     uint32_t* const acc = reinterpret_cast<uint32_t*>(lds);
     uint8_t* const un = lds + L::kAcc;
@@ -580,11 +626,12 @@ __global__ __launch_bounds__(NT, MIN_WAVES) void hybrid_tiles(const ScoreArgs a,
     uint32_t* const tmax = reinterpret_cast<uint32_t*>(un + L::kUnion);
     uint32_t* const wmax = tmax + NT;
     SelectScratch& ss = *reinterpret_cast<SelectScratch*>(un + L::kUnion + L::kTmax);
-    uint32_t* const hist = reinterpret_cast<uint32_t*>(un);
-    uint64_t* const hcand = reinterpret_cast<uint64_t*>(un + kHistBins * 4);
+    uint32_t* const hist = reinterpret_cast<uint32_t*>(un);            // [2][kHistBins]: sparse, dense
+    uint64_t* const cands = reinterpret_cast<uint64_t*>(un);           // [2][kHistCand] once the scan is over
     HistScratch& hs = *reinterpret_cast<HistScratch*>(tmax);
 
     const uint32_t tid = threadIdx.x;
+    const uint32_t lane = tid & 63, wave = rfl(tid >> 6);
     // diagnostic instance only (MSR_DEBUG_HYBRID): wave 0 of one workgroup in 64 adds its clock deltas per phase
     long long t_prev = 0;
     auto stamp = [&](int slot) {
@@ -599,76 +646,339 @@ __global__ __launch_bounds__(NT, MIN_WAVES) void hybrid_tiles(const ScoreArgs a,
     const uint32_t ndocs = (uint32_t)a.n_docs;  // single tile
     const int rounds = (int)((ndocs + 4 * NT - 1) / (4 * NT));
     uint4* const a4 = reinterpret_cast<uint4*>(acc);
+    if (tid < 8) ds.red[tid] = 0;  // (ordered before their first use by accumulate_tile's barriers)
+    if (tid < 2) ds.ncand[tid] = 0;
+    if (tid == 0) ds.fn = 0;
     accumulate_tile<TILE_DOCS, NT, U, false>(a, q, 0u, rounds, lds, ss, [](int) {}, tid);
     stamp(0);
 
-    // the query's row of dense keys (the GEMM wrote it in ordinal order; docs past the corpus hold key 0 or, beyond
-    // the GEMM's last doc block, nothing): requested now, in flight during the sparse selection
-    uint32_t dk[E];
+    // ---- the query's row of dense scores (the GEMM wrote order-preserving keys in ORDINAL order) as floats in
+    // registers; docs past the corpus become NaN: min / max skip them, every comparison with them is false
+    float df[E];
     {
         const uint4* row = reinterpret_cast<const uint4*>(h.dkeys + (uint64_t)blockIdx.x * h.ld);
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             const uint4 x = r < rounds ? row[r * NT + tid] : make_uint4(0, 0, 0, 0);
-            dk[4 * r + 0] = x.x, dk[4 * r + 1] = x.y, dk[4 * r + 2] = x.z, dk[4 * r + 3] = x.w;
+            const uint32_t k4[4] = {x.x, x.y, x.z, x.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const uint32_t local = 4u * ((uint32_t)r * NT + tid) + (uint32_t)e;
+                // (+ 0.0f: -0 and +0 are one score; they would be two keys)
+                df[4 * r + e] = (r < rounds && local < ndocs) ? key_to_f32(k4[e]) + 0.0f : __builtin_nanf("");
+            }
         }
     }
-    // ---- list membership: the depth best of each side (ties to the lower ordinal, like every list in this library).
-    // First-level bins: linear in the integer score / in the float VALUE of the dense score. The sparse scores stay in
-    // the LDS tile and are re-read per pass (accumulators of docs past the corpus are 0 by construction).
-    const HistResult hsp = hist_threshold<TILE_DOCS, NT>(
-        [&](int r) { return r < rounds ? a4[r * NT + tid] : make_uint4(0, 0, 0, 0); }, h.depth, hist, hcand, hs, tid,
-        [](uint32_t key, uint32_t lo) { return (float)(key - lo); });
-    stamp(1);
+    // zero both histograms (the staging arrays of the accumulation lived here)
+    for (int i = tid; i < 2 * kHistBins / 4; i += NT) reinterpret_cast<uint4*>(hist)[i] = make_uint4(0, 0, 0, 0);
+    // ---- pass A: present sparse scores (count, max, min) and dense scores (max, min)
+    {
+        uint32_t smx = 0, smn1 = 0xFFFFFFFFu, scnt = 0;
+        float dmx = -__builtin_inff(), dmn = __builtin_inff();
 #pragma unroll
-    for (int j = 0; j < E; ++j) {
-        const uint32_t local = 4u * ((uint32_t)(j / 4) * NT + tid) + (uint32_t)(j % 4);
-        if (local >= ndocs) dk[j] = 0;
+        for (int r = 0; r < R; ++r)
+            if (r < rounds) {
+                const uint4 x = a4[r * NT + tid];
+                const uint32_t s4[4] = {x.x, x.y, x.z, x.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    smx = max(smx, s4[e]);
+                    smn1 = min(smn1, s4[e] - 1u);  // an absent score (0) wraps to the largest value
+                    scnt += min(s4[e], 1u);
+                    dmx = fmaxf(dmx, df[4 * r + e]);
+                    dmn = fminf(dmn, df[4 * r + e]);
+                }
+            }
+        smx = wave_max_u32(smx);
+        smn1 = wave_max_u32(~smn1);
+        scnt = wave_sum_u32(scnt);
+        const uint32_t kx = wave_max_u32(f32_to_key(dmx)), kn = wave_max_u32(~f32_to_key(dmn));
+        if (lane == 0) {
+            atomicMax(&ds.red[0], smx);
+            atomicMax(&ds.red[1], smn1);
+            atomicAdd(&ds.red[2], scnt);
+            atomicMax(&ds.red[3], kx);
+            atomicMax(&ds.red[4], kn);
+        }
     }
-    const HistResult hde = hist_threshold<TILE_DOCS, NT>(
-        [&](int r) { return make_uint4(dk[4 * r], dk[4 * r + 1], dk[4 * r + 2], dk[4 * r + 3]); }, h.depth, hist, hcand, hs,
-        tid, [](uint32_t key, uint32_t lo) { return key_to_f32(key) - key_to_f32(lo); });
-    stamp(2);
-    // min / max of each run as get_run_dict records them (src/search.py:76-81): over the whole list
-    const bool has_s = hsp.n != 0, has_d = hde.n != 0;
-    const uint32_t smin_k = hsp.T > 1 ? (uint32_t)(hsp.T >> 13) : hsp.kmin, dmin_k = hde.T > 1 ? (uint32_t)(hde.T >> 13) : hde.kmin;
-    const float smin = has_s ? (float)smin_k : 0.f, smax = has_s ? (float)hsp.kmax : 0.f;
-    const float dmin = has_d ? key_to_f32(dmin_k) : 0.f, dmax = has_d ? key_to_f32(hde.kmax) : 0.f;
+    __syncthreads();
+    const uint32_t smax_u = ds.red[0], n_s = ds.red[2];
+    const uint32_t smin_u = n_s ? ~ds.red[1] + 1u : 0u;
+    const uint32_t n_d = ndocs;  // every doc has a dense score
+    const float dmax_f = key_to_f32(ds.red[3]), dmin_all = key_to_f32(~ds.red[4]);
+    // list sizes: the depth best, or everything that is present
+    const uint32_t need_s = min(h.depth, n_s), need_d = min(h.depth, n_d);
+    // ---- pass B: histograms, linear between the smallest and the largest present value of each side
+    const float sc_s = ((float)kHistBins - 0.5f) / (float)(smax_u - smin_u);
+    const float sc_d = ((float)kHistBins - 0.5f) / (dmax_f - dmin_all);
+    const bool flat_s = smax_u == smin_u, flat_d = !(dmax_f > dmin_all);  // all equal: no spread to bin on
+    auto pack_u16 = [](uint32_t lo, uint32_t hi) -> uint32_t {
+        typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+        return __builtin_bit_cast(uint32_t, (us2)__builtin_amdgcn_cvt_pk_u16(lo, hi));  // v_cvt_pk_u16_u32 saturates
+    };
+    uint32_t bins[E];  // sparse bin | dense bin << 16
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+        if (r < rounds) {
+            const uint4 x = a4[r * NT + tid];
+            const uint32_t s4[4] = {x.x, x.y, x.z, x.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const uint32_t bs = (uint32_t)((float)(s4[e] - smin_u) * sc_s);
+                const uint32_t bd = (uint32_t)((df[4 * r + e] - dmin_all) * sc_d);
+                // branch-free: an absent element adds 0 to whatever bin its garbage maps to (no exec-mask juggling per
+                // element; nearly every doc is present on both sides)
+                atomicAdd(&hist[bs & (kHistBins - 1)], flat_s ? 0u : min(s4[e], 1u));
+                atomicAdd(&hist[kHistBins + (bd & (kHistBins - 1))], (df[4 * r + e] == df[4 * r + e] && !flat_d) ? 1u : 0u);
+                bins[4 * r + e] = pack_u16(bs, bd);  // (saturating: an absent score's bin is garbage)
+            }
+        }
+    __syncthreads();
+    // ---- scan: waves [0, HW) walk the sparse bins from the top, waves [HW, NW) the dense bins; the thread whose bins
+    // hold the need-th best publishes {bin, elements above it, elements in it}
+    {
+        const uint32_t side = wave >= (uint32_t)HW ? 1u : 0u;
+        const uint32_t t2 = tid - side * (HW * 64);  // thread index inside its half
+        const uint32_t need = side ? need_d : need_s;
+        const uint32_t* hb_base = hist + side * kHistBins + (kHistBins - BPT) - BPT * t2;  // bins ascending in memory
+        uint32_t hb[BPT];  // descending bin order
+        {
+            const uint4 v = *reinterpret_cast<const uint4*>(hb_base + (BPT - 4));
+            hb[0] = v.w, hb[1] = v.z, hb[2] = v.y, hb[3] = v.x;
+            if (BPT == 8) {
+                const uint4 u = *reinterpret_cast<const uint4*>(hb_base);
+                hb[BPT - 4] = u.w, hb[BPT - 3] = u.z, hb[BPT - 2] = u.y, hb[BPT - 1] = u.x;
+            }
+        }
+        uint32_t s = 0;
+#pragma unroll
+        for (int i = 0; i < BPT; ++i) s += hb[i];
+        const uint32_t inc = wave_inclusive_scan_u32(s);
+        if (lane == 63) ds.wtot[side][wave - side * HW] = inc;
+        __syncthreads();
+        uint32_t above = inc - s;
+#pragma unroll
+        for (int w = 0; w < HW; ++w) above += (uint32_t)w < wave - side * HW ? ds.wtot[side][w] : 0u;
+        if (above < need && need <= above + s) {  // exactly one thread per side (none when the side is flat / empty)
+            uint32_t b = 0, ab = above;
+#pragma unroll
+            for (int i = 0; i < BPT - 1; ++i)
+                if (b == (uint32_t)i && ab + hb[i] < need) {
+                    ab += hb[i];
+                    b = (uint32_t)i + 1;
+                }
+            uint32_t cnt = hb[0];
+#pragma unroll
+            for (int i = 1; i < BPT; ++i) cnt = b == (uint32_t)i ? hb[i] : cnt;
+            ds.bin[side] = (uint32_t)(kHistBins - 1) - (BPT * t2 + b);
+            ds.above[side] = ab;
+            ds.cnt[side] = cnt;
+        }
+    }
+    __syncthreads();
+    // ---- pass C: the chosen bins' elements as composites  key << 13 | (TILE_DOCS - 1 - local)  (ties: lower ordinal)
+    const uint32_t bsel_s = ds.bin[0], bsel_d = ds.bin[1], cnt_s = ds.cnt[0], cnt_d = ds.cnt[1];
+    const bool fast_s = !flat_s && n_s != 0 && cnt_s <= (uint32_t)kHistCand;
+    const bool fast_d = !flat_d && cnt_d <= (uint32_t)kHistCand;
+    {
+        // which of this thread's elements sit in a chosen bin: bit j (sparse), bit 16 + j (dense); almost always none
+        const uint32_t want = pack_u16(fast_s ? bsel_s : 0xFFFEu, fast_d ? bsel_d : 0xFFFEu);
+        uint32_t hit = 0;
+#pragma unroll
+        for (int j = 0; j < E; ++j) {
+            const uint32_t x = bins[j] ^ want;  // a zero half = that side's bin matches
+            hit |= ((x & 0xFFFFu) == 0 ? 1u : 0u) << j;
+            hit |= ((x >> 16) == 0 ? 1u : 0u) << (16 + j);
+        }
+        if (hit) {
+#pragma unroll
+            for (int r = 0; r < R; ++r)
+                if (r < rounds) {
+                    const uint4 x = a4[r * NT + tid];
+                    const uint32_t s4[4] = {x.x, x.y, x.z, x.w};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int j = 4 * r + e;
+                        const uint64_t inv = (uint64_t)(TILE_DOCS - 1 - (4u * ((uint32_t)r * NT + tid) + (uint32_t)e));
+                        if ((hit >> j & 1u) && s4[e] != 0)
+                            cands[atomicAdd(&ds.ncand[0], 1u)] = ((uint64_t)s4[e] << 13) | inv;
+                        if ((hit >> (16 + j) & 1u) && df[j] == df[j])
+                            cands[kHistCand + atomicAdd(&ds.ncand[1], 1u)] = ((uint64_t)f32_to_key(df[j]) << 13) | inv;
+                    }
+                }
+        }
+    }
+    __syncthreads();
+    // ---- exact rank inside the chosen bin: one wave per side while the bin holds <= 64 elements
+    auto rank_side = [&](uint32_t side, uint32_t cnt, uint32_t need_in_bin) {
+        const uint64_t* c = cands + side * kHistCand;
+        if (cnt <= 64) {
+            if (wave == side * HW) {
+                const uint64_t me = lane < cnt ? c[lane] : 0ull;
+                const uint32_t lo = (uint32_t)me, hi = (uint32_t)(me >> 32);
+                uint32_t rank = 0;
+                for (uint32_t i = 0; i < cnt; ++i) {
+                    const uint64_t o = ((uint64_t)rdl(hi, i) << 32) | rdl(lo, i);
+                    rank += o > me;
+                }
+                if (lane < cnt && rank == need_in_bin - 1) ds.T[side] = me;
+            }
+        } else {
+            for (uint32_t i = tid; i < cnt; i += NT) {
+                const uint64_t me = c[i];
+                uint32_t rank = 0;
+                for (uint32_t o = 0; o < cnt; ++o) rank += c[o] > me;
+                if (rank == need_in_bin - 1) ds.T[side] = me;
+            }
+        }
+    };
+    if (fast_s) rank_side(0, cnt_s, need_s - ds.above[0]);
+    if (fast_d) rank_side(1, cnt_d, need_d - ds.above[1]);
+    __syncthreads();
+    uint64_t T_s = ds.T[0], T_d = ds.T[1];
+    // ---- rare: a side without spread, or a bin with more than kHistCand elements (mass ties): the general selection
+    if (n_s != 0 && !fast_s)  // (uniform)
+        T_s = threshold_general<TILE_DOCS, NT>(acc, rounds, ndocs, h.depth, false, hist, cand + kHistBins / 2, &hs, tid);
+    if (!fast_d)
+        T_d = threshold_general<TILE_DOCS, NT>(h.dkeys + (uint64_t)blockIdx.x * h.ld, rounds, ndocs, h.depth, true, hist,
+                                               cand + kHistBins / 2, &hs, tid);
+    stamp(1);
+    // ---- fusion (src/hybrid.py:32-53): min = the last member's score, max = the best, per side; fused keys go to the
+    // accumulator tile (each thread rewrites only what it has read) and into a histogram over [fmin, fmax]
+    const uint32_t ts_key = (uint32_t)(T_s >> 13), ts_inv = (uint32_t)T_s & 8191u;
+    const uint32_t td_inv = (uint32_t)T_d & 8191u;
+    const float td_f = key_to_f32((uint32_t)(T_d >> 13)) + 0.0f;
+    const float smin = n_s ? (float)ts_key : 0.f, smax = n_s ? (float)smax_u : 0.f;
+    const float dmin = td_f, dmax = dmax_f;
     const float sden = fmaxf(smax - smin, 1e-9f), dden = fmaxf(dmax - dmin, 1e-9f);
     const uint32_t self = h.self_ord ? (uint32_t)h.self_ord[q] : 0xFFFFFFFFu;
-    uint32_t sv[E];
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-        const uint4 x = r < rounds ? a4[r * NT + tid] : make_uint4(0, 0, 0, 0);
-        sv[4 * r + 0] = x.x, sv[4 * r + 1] = x.y, sv[4 * r + 2] = x.z, sv[4 * r + 3] = x.w;
-    }
-    // (each thread rewrites only the accumulators it has just read; the selection scratch is dead)
+    // fused scores lie in [min(w,0) sums, max(w,0) sums]
+    const float f_lo = fminf(h.w_dense, 0.f) + fminf(h.w_sparse, 0.f), f_hi = fmaxf(h.w_dense, 0.f) + fmaxf(h.w_sparse, 0.f);
+    const float sc_f = ((float)kHistBins - 0.5f) / fmaxf(f_hi - f_lo, 1e-30f);
+    // (x - min) * (w / den) instead of w * ((x - min) / den): one multiplication per term, 1-2 ulp from the reference's
+    // order of operations, far inside the 1e-5 the fused scores are held to
+    const float cd = h.w_dense / dden, cs = h.w_sparse / sden;
+    for (int i = tid; i < kHistBins / 4; i += NT) reinterpret_cast<uint4*>(hist)[i] = make_uint4(0, 0, 0, 0);
     if (tid < 64) ss.cnt[tid] = 0;
     if (tid == 0) {
         ss.n_cand = 0;
         ss.tau0 = 1;
         ss.smax = 0;
     }
+    __syncthreads();  // histogram zeroed (the candidate lists that lived there are dead)
+    uint32_t fkeys[E];
+    uint32_t n_mem = 0;
 #pragma unroll
-    for (int r = 0; r < R; ++r) {
-        uint32_t fk[4];
+    for (int r = 0; r < R; ++r)
+        if (r < rounds) {
+            const uint4 x = a4[r * NT + tid];
+            const uint32_t s4[4] = {x.x, x.y, x.z, x.w};
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int j = 4 * r + e;
-            const uint32_t local = 4u * ((uint32_t)r * NT + tid) + (uint32_t)e;
-            const uint64_t inv = (uint64_t)(TILE_DOCS - 1 - local);
-            const bool in_d = dk[j] != 0 && (((uint64_t)dk[j] << 13) | inv) >= hde.T;
-            const bool in_s = sv[j] != 0 && (((uint64_t)sv[j] << 13) | inv) >= hsp.T;
-            float f = 0.f;  // the reference adds the dense term first (runs = [dense, sparse], src/search.py:459)
-            if (in_d) f += h.w_dense * ((key_to_f32(dk[j]) - dmin) / dden);
-            if (in_s) f += h.w_sparse * (((float)sv[j] - smin) / sden);
-            fk[e] = ((in_d || in_s) && local != self) ? f32_to_key(f) : 0u;
+            for (int e = 0; e < 4; ++e) {
+                const uint32_t local = 4u * ((uint32_t)r * NT + tid) + (uint32_t)e;
+                const uint32_t inv = (uint32_t)(TILE_DOCS - 1) - local;
+                const float d = df[4 * r + e];
+                const bool in_d = d > td_f || (d == td_f && inv >= td_inv);
+                const bool in_s = s4[e] != 0 && (s4[e] > ts_key || (s4[e] == ts_key && inv >= ts_inv));
+                float f = 0.f;  // the reference adds the dense term first (runs = [dense, sparse], src/search.py:459)
+                if (in_d) f += (d - dmin) * cd;
+                if (in_s) f += ((float)s4[e] - smin) * cs;
+                const bool member = (in_d || in_s) && local != self;
+                fkeys[4 * r + e] = member ? f32_to_key(f) : 0u;
+                const uint32_t fb = (uint32_t)((f - f_lo) * sc_f);
+                bins[4 * r + e] = member ? fb : 0xFFFFFFFFu;  // (the selection bins are dead: reuse the registers)
+                if (member) {
+                    atomicAdd(&hist[fb], 1u);
+                    ++n_mem;
+                }
+            }
+            a4[r * NT + tid] = make_uint4(fkeys[4 * r], fkeys[4 * r + 1], fkeys[4 * r + 2], fkeys[4 * r + 3]);
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) fkeys[4 * r + e] = 0, bins[4 * r + e] = 0xFFFFFFFFu;
         }
-        if (r < rounds) a4[r * NT + tid] = make_uint4(fk[0], fk[1], fk[2], fk[3]);
+    n_mem = wave_sum_u32(n_mem);
+    if (lane == 0) atomicAdd(&ds.red[5], n_mem);
+    __syncthreads();
+    stamp(2);
+    // ---- top-k of the fused scores: the bin of the k-th best, then every member at or above that bin is ranked
+    const uint32_t n_members = ds.red[5];
+    const uint32_t need_f = min(h.k, n_members);
+    {
+        const bool scans = wave < (uint32_t)HW;  // the first half of the workgroup walks the bins
+        const uint32_t t2 = scans ? tid : 0u;
+        const uint32_t* hb_base = hist + (kHistBins - BPT) - BPT * t2;
+        uint32_t hb[BPT];
+        {
+            const uint4 v = *reinterpret_cast<const uint4*>(hb_base + (BPT - 4));
+            hb[0] = v.w, hb[1] = v.z, hb[2] = v.y, hb[3] = v.x;
+            if (BPT == 8) {
+                const uint4 u = *reinterpret_cast<const uint4*>(hb_base);
+                hb[BPT - 4] = u.w, hb[BPT - 3] = u.z, hb[BPT - 2] = u.y, hb[BPT - 1] = u.x;
+            }
+        }
+        uint32_t s = 0;
+#pragma unroll
+        for (int i = 0; i < BPT; ++i) s += hb[i];
+        const uint32_t inc = wave_inclusive_scan_u32(s);
+        if (scans && lane == 63) ds.wtot[0][wave] = inc;
+        __syncthreads();
+        uint32_t above = inc - s;
+#pragma unroll
+        for (int w = 0; w < HW; ++w) above += (uint32_t)w < wave ? ds.wtot[0][w] : 0u;
+        if (scans && need_f != 0 && above < need_f && need_f <= above + s) {
+            uint32_t b = 0, ab = above;
+#pragma unroll
+            for (int i = 0; i < BPT - 1; ++i)
+                if (b == (uint32_t)i && ab + hb[i] < need_f) {
+                    ab += hb[i];
+                    b = (uint32_t)i + 1;
+                }
+            uint32_t cnt = hb[0];
+#pragma unroll
+            for (int i = 1; i < BPT; ++i) cnt = b == (uint32_t)i ? hb[i] : cnt;
+            ds.fbin = (uint32_t)(kHistBins - 1) - (BPT * tid + b);
+            ds.fabove = ab;
+            ds.fcnt = cnt;
+        }
     }
     __syncthreads();
-    stamp(3);
-    tile_select<TILE_DOCS, NT, CAND>(a4, cand, tmax, wmax, ss, rounds, 0ull, (int)h.k, res, [](int) {}, tid);
+    const uint32_t n_top = need_f ? ds.fabove + ds.fcnt : 0u;  // members at or above the k-th best's bin
+    if (n_top <= 64) {
+        // the usual case: a handful of members; one wave ranks them and writes the result rows
+        const uint32_t fbin = ds.fbin;
+        uint64_t* const top = reinterpret_cast<uint64_t*>(tmax);  // 64 keys
+#pragma unroll
+        for (int j = 0; j < E; ++j)
+            if (need_f && bins[j] != 0xFFFFFFFFu && bins[j] >= fbin) {
+                const uint32_t local = 4u * ((uint32_t)(j / 4) * NT + tid) + (uint32_t)(j % 4);
+                top[atomicAdd(&ds.fn, 1u)] = ((uint64_t)fkeys[j] << 32) | (uint64_t)(0xFFFFFFFFu - local);
+            }
+        __syncthreads();
+        if (tid < 64) {
+            const uint64_t me = tid < n_top ? top[tid] : 0ull;
+            const uint32_t lo = (uint32_t)me, hi = (uint32_t)(me >> 32);
+            uint32_t rank = 0;
+            for (uint32_t i = 0; i < n_top; ++i) {
+                const uint64_t o = ((uint64_t)rdl(hi, i) << 32) | rdl(lo, i);
+                rank += o > me;
+            }
+            const uint64_t o = (uint64_t)q * h.k;
+            if (tid < n_top && rank < h.k) {
+                h.out_ord[o + rank] = 0xFFFFFFFFu - (uint32_t)me;
+                h.out_score[o + rank] = key_to_f32((uint32_t)(me >> 32));
+            }
+            if (tid >= need_f && tid < h.k) {
+                h.out_ord[o + tid] = 0xFFFFFFFFu;
+                h.out_score[o + tid] = 0.f;
+            }
+            if (tid == 0) h.out_n[q] = (int32_t)need_f;
+        }
+        stamp(3);
+        return;
+    }
+    // ---- rare (many equal fused scores around the k-th place): the general tile selection over the fused keys
+    tile_select_general<TILE_DOCS, NT, CAND>(a4, cand, tmax, wmax, &ss, rounds, (int)h.k, res, tid);
     __syncthreads();
     stamp(4);
     if (tid < h.k) {
@@ -694,9 +1004,8 @@ __global__ __launch_bounds__(256) void permute_rows(const uint4* __restrict__ sr
 
 }  // namespace msr
 
-// The fused path of msr_hybrid_search (single-tile indexes, k <= 64): per chunk of queries one GEMM launch on the
-// ordinal-permuted passage matrix, then hybrid_tiles; the chunk's score rows (<= 192 MB) stay in the Infinity Cache
-// between the two. ms = {fused scoring + selection + fusion kernel, dense GEMM, 0, 0}.
+// The fused path of msr_hybrid_search (single-tile indexes, k <= 64): per chunk of queries (normally ONE chunk) a GEMM
+// launch on the ordinal-permuted passage matrix, then hybrid_tiles. ms = {fused scoring + selection + fusion kernel, dense GEMM, 0, 0}.
 static int hybrid_search_fused(msr_index* ix, msr_dense* dx, const int64_t* q_ptr, const int32_t* q_term, const int32_t* q_w,
                                const uint16_t* q_fp16, int nq, int depth, int k, float alpha, uint32_t flags,
                                const uint32_t* row2ord, const int32_t* self_ord, uint32_t* out_ord, float* out_score,
@@ -746,11 +1055,16 @@ static int hybrid_search_fused(msr_index* ix, msr_dense* dx, const int64_t* q_pt
     const uint64_t ld = (n + 4 * nt_threads - 1) / (4 * nt_threads) * (4 * nt_threads);  // whole select rounds
     const uint64_t n_cover = std::min<uint64_t>(dx->n_pad, (n + 255) / 256 * 256);
     const uint32_t col_blocks = (uint32_t)(n_cover / 256);
-    // queries per chunk: two rounds of the chip's 256 CUs worth of 256 x 256 blocks, score rows <= 192 MB
-    uint32_t row_blocks = std::max<uint32_t>(1u, 512u / std::max(col_blocks, 1u));
-    row_blocks = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(row_blocks, (192ull << 20) / (ld * 4 * 256)));
-    const uint32_t qc = row_blocks * 256;
+    // queries per chunk: everything when the score rows fit 2 GiB (one GEMM launch: the least tail and launch gaps; the
+    // round trip of the rows through HBM is ~0.25 GB per 6 400 queries — noise next to either kernel), else chunks of
+    // whole rounds of the chip's 256 CUs worth of 256 x 256 blocks
     const uint32_t nq_pad = (uint32_t)((nq + 255) / 256 * 256);
+    // queries per chunk: whole rounds of the chip's 256 CUs worth of 256 x 256 GEMM blocks, score rows <= ~160 MB so
+    // that hybrid_tiles finds its row in the Infinity Cache (the row load is a dependent fetch at the start of the
+    // epilogue: from HBM the same kernel measured 1.66 ms instead of 1.30 ms per 25 010 queries)
+    uint64_t row_blocks = std::max<uint64_t>(1, (160ull << 20) / (ld * 4 * 256));
+    if (col_blocks && row_blocks * col_blocks >= 256) row_blocks = row_blocks * col_blocks / 256 * 256 / col_blocks;
+    const uint32_t qc = (uint32_t)std::min<uint64_t>(row_blocks * 256, std::max<uint32_t>(nq_pad, 256u));
     _Float16* d_Q = nullptr;
     uint32_t* d_S = nullptr;
     uint32_t* d_ord = nullptr;
@@ -809,6 +1123,13 @@ static int hybrid_search_fused(msr_index* ix, msr_dense* dx, const int64_t* q_pt
     ha.out_ord = d_ord;
     ha.out_score = d_sf;
     ha.out_n = d_n;
+    static const bool inner_events = getenv("MSR_HYBRID_NO_INNER_EVENTS") == nullptr;
+    hipEvent_t e_all[2] = {nullptr, nullptr};
+    if (rc == MSR_OK && (hipEventCreate(&e_all[0]) != hipSuccess || hipEventCreate(&e_all[1]) != hipSuccess)) {
+        set_error("hipEventCreate failed");
+        rc = MSR_E_HIP;
+    }
+    if (rc == MSR_OK) (void)hipEventRecord(e_all[0], d->stream);
     for (uint32_t q0 = 0; q0 < (uint32_t)nq && rc == MSR_OK; q0 += qc) {
         const uint32_t qn = std::min<uint32_t>(qc, (uint32_t)nq - q0);
         const uint32_t qn_pad = (qn + 255) / 256 * 256;
@@ -821,10 +1142,10 @@ static int hybrid_search_fused(msr_index* ix, msr_dense* dx, const int64_t* q_pt
             set_error("hipEventCreate failed");
             break;
         }
-        (void)hipEventRecord(e[0], d->stream);
+        if (inner_events) (void)hipEventRecord(e[0], d->stream);
         rc = launch_dense_gemm(dx, dx->d_P_ord, d_Q + (size_t)q0 * dx->h, d_S, qn, qn_pad, n_cover, ld, d->stream, true);
         if (rc != MSR_OK) break;
-        (void)hipEventRecord(e[1], d->stream);
+        if (inner_events) (void)hipEventRecord(e[1], d->stream);
         sa.q0 = q0;
         sa.qn = qn;
         sa.stamps = d_stamps;
@@ -839,14 +1160,17 @@ static int hybrid_search_fused(msr_index* ix, msr_dense* dx, const int64_t* q_pt
             rc = MSR_E_HIP;
             break;
         }
-        (void)hipEventRecord(e[2], d->stream);
+        if (inner_events) (void)hipEventRecord(e[2], d->stream);
     }
+    if (rc == MSR_OK) (void)hipEventRecord(e_all[1], d->stream);
     if (rc == MSR_OK && hipStreamSynchronize(d->stream) != hipSuccess) {
         set_error("hybrid kernels failed: %s", hipGetErrorString(hipGetLastError()));
         rc = MSR_E_HIP;
     }
-    float t_gemm = 0, t_fused = 0;
-    if (rc == MSR_OK) {
+    float t_gemm = 0, t_fused = 0, t_all = 0;
+    if (rc == MSR_OK) (void)hipEventElapsedTime(&t_all, e_all[0], e_all[1]);
+    if (getenv("MSR_DEBUG_HYBRID")) fprintf(stderr, "[msr] hybrid pipeline span %.3f ms (inner events %d)\n", t_all, (int)inner_events);
+    if (rc == MSR_OK && inner_events) {
         for (size_t i = 0; i + 2 < ev.size(); i += 3) {
             float a = 0, c = 0;
             (void)hipEventElapsedTime(&a, ev[i], ev[i + 1]);
@@ -875,6 +1199,8 @@ static int hybrid_search_fused(msr_index* ix, msr_dense* dx, const int64_t* q_pt
         (void)hipFree(d_stamps);
     }
     for (hipEvent_t x : ev)
+        if (x) (void)hipEventDestroy(x);
+    for (hipEvent_t x : e_all)
         if (x) (void)hipEventDestroy(x);
     void* ptrs[] = {d_Q, d_S, d_ord, d_sf, d_n, d_self};
     for (void* p2 : ptrs)

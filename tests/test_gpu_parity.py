@@ -600,7 +600,7 @@ def test_c5_real_shape_dense_and_hybrid_vs_oracle_pipeline(m, tmp_path):
         ords, fs, cnt, ms = hybrid_search(ix, dix, qp, qt, qw, q, depth, k, alpha, r2o)
         got_ids = {int(i): ix.docids(ords[i, :cnt[i]]) for i in sample}
         dix.close()
-    assert ms["dense_gemm"] > 0 and ms["fusion"] > 0
+    assert ms["dense_gemm"] > 0 and ms["sparse"] > 0 and ms["fusion"] == 0   # one tile: the fused kernel
     # (a) dense top-1000 of the sampled queries
     ws, wi = _dense_oracle(q[sample], p, depth)
     assert np.abs(d_scores[sample] - ws).max() <= 1e-5
