@@ -137,6 +137,10 @@ def _cmd_search(a):
         if not dist.is_initialized():
             dist.init_process_group("gloo")
         a.device = int(os.environ.get("LOCAL_RANK", "0"))
+        if os.environ.get("MSR_SHARE_GPU"):  # rehearsal on a box with fewer GPUs than ranks: ranks share the devices
+            import torch
+
+            a.device %= max(torch.cuda.device_count(), 1)
     searcher = LuceneImpactSearcher(os.path.join(a.sparse_index, "index") if os.path.isdir(
         os.path.join(a.sparse_index, "index")) else a.sparse_index, None, device=a.device)
     searcher.set_analyzer(JWhiteSpaceAnalyzer())

@@ -115,13 +115,31 @@ __global__ __launch_bounds__(256) void dense_scores(const _Float16* __restrict__
 // distinct banks. Used when the grid fills the chip (>= 256 blocks) and H % 64 == 0; otherwise the 128 x 128 kernel.
 constexpr int kG2Stage = 2 * 256 * 128;  // bytes per stage: A rows then B rows, 128 B (64 halves) each
 
+// Block -> tile map: a 2-D grid (x = query block, y = doc block) when `db_n` is 0; else a 1-D grid that is XCD-aware:
+// workgroup L runs on XCD L % 8 (round-robin dispatch) as that XCD's (L / 8)-th block, and every XCD walks its own
+// contiguous EIGHTH of the block list in patch-major order (patches of 8 query blocks x 4 doc blocks). The 32 blocks
+// resident together on an XCD (one per CU) are then one patch or the seam of two: per K step they share about 8 + 4
+// operand slabs of 32 KB through that XCD's L2 instead of fetching 2 x 32 — and all XCDs get the same number of blocks
+// (a patch grid dealt out patch by patch was 26 % SLOWER: 20 patches over 8 XCDs is 3 rounds for some, 2 for others).
 __global__ __launch_bounds__(512, 1) void dense_scores_256(const _Float16* __restrict__ Q, const _Float16* __restrict__ P,
                                                            uint32_t* __restrict__ out, uint32_t M, uint32_t N, uint32_t H,
-                                                           uint64_t ld) {
+                                                           uint64_t ld, uint32_t qb_n, uint32_t db_n) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];  // 2 stages
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t r = lane & 31, h = lane >> 5;
-    const uint32_t q_blk = blockIdx.x * 256, d_blk = blockIdx.y * 256;
+    uint32_t qb = blockIdx.x, db = blockIdx.y;
+    if (db_n) {
+        const uint32_t n_blk = qb_n * db_n, per = (n_blk + 7u) / 8u;
+        const uint32_t xcd = blockIdx.x & 7u, slot = blockIdx.x >> 3;
+        const uint32_t t = xcd * per + slot;  // position in the patch-major order of all blocks
+        if (slot >= per || t >= n_blk) return;
+        const uint32_t pr = t / (8u * db_n), rem = t - pr * 8u * db_n;
+        const uint32_t hp = min(8u, qb_n - 8u * pr);  // query blocks in this patch row (the last one may be short)
+        const uint32_t pc = rem / (hp * 4u), rem2 = rem - pc * hp * 4u;
+        qb = pr * 8u + rem2 % hp;
+        db = pc * 4u + rem2 / hp;
+    }
+    const uint32_t q_blk = qb * 256, d_blk = db * 256;
     if (d_blk >= N) {  // padding docs that select_tiles still reads: keys 0
         for (uint32_t i = tid; i < 256 * 64; i += 512) {
             const uint32_t q = q_blk + i / 64;
@@ -279,9 +297,14 @@ static int launch_dense_gemm(msr_dense* dx, const _Float16* P, const _Float16* d
     for (uint64_t d0 = 0; d0 < n_cover; d0 += blk * kMaxGridY) {
         const uint64_t nd = std::min<uint64_t>(n_cover - d0, blk * kMaxGridY);
         const uint32_t n_left = dx->n > d0 ? (uint32_t)std::min<uint64_t>(dx->n - d0, 0xFFFFFFFFull) : 0u;
-        if (big)
+        static const bool no_patch = getenv("MSR_GEMM_NO_PATCH") != nullptr;  // diagnostic: the plain 2-D grid
+        if (big && !no_patch) {
+            const uint32_t qb_n = qn_pad / 256, db_n = (uint32_t)(nd / 256);
+            hipLaunchKernelGGL(dense_scores_256, dim3((qb_n * db_n + 7) / 8 * 8), dim3(512), 2 * kG2Stage, st, d_Q,
+                               P + d0 * dx->h, d_S + d0, qn, n_left, dx->h, ld, qb_n, db_n);
+        } else if (big)
             hipLaunchKernelGGL(dense_scores_256, dim3(qn_pad / 256, (uint32_t)(nd / 256)), dim3(512), 2 * kG2Stage, st, d_Q,
-                               P + d0 * dx->h, d_S + d0, qn, n_left, dx->h, ld);
+                               P + d0 * dx->h, d_S + d0, qn, n_left, dx->h, ld, 0u, 0u);
         else
             hipLaunchKernelGGL(dense_scores, dim3(qn_pad / 128, (uint32_t)(nd / 128)), dim3(256), 0, st, d_Q, P + d0 * dx->h,
                                d_S + d0, qn, n_left, dx->h, ld);

@@ -255,6 +255,55 @@ def test_cli_search_end_to_end(m, tmp_path, capsys):
     assert os.path.exists(tmp_path / "runs2" / "fusion.trec")
 
 
+def test_cli_search_two_ranks_dp_over_queries(m, tmp_path):
+    """`search` under a launcher = the reference's DP over queries (src/search.py:115-129,180-182; launcher line
+    scripts/search_sparse.sh:14): two ranks (sharing this box's one GPU), each searches its DistributedSampler shard, only
+    recall fractions are gathered. The merged TREC run equals the single-process run, the summed recall equals the
+    single-process recall (true denominator), and --compat-denominator reproduces the padded denominator."""
+    import subprocess
+    import sys
+
+    from mllm_sparse_retrieval_amd import cli
+
+    enc = str(tmp_path / "enc")
+    cli.main(["encode", "--synthetic", "flickr", "--n_images", "201", "--sparse_output_dir", enc, "--threads", "4"])
+    cli.main(["index", "--input", enc, "--threads", "4"])
+    common = ["--sparse_index", enc, "--depth", "10", "--batch_size", "128", "--query_type", "text", "--dataset_name",
+              "flickr", "--qrels", os.path.join(enc, "qrels.csv")]
+
+    def run(world, extra, save):
+        env = dict(os.environ, MSR_SHARE_GPU="1", PYTHONPATH=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        for k2 in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+            env.pop(k2, None)
+        cmd = [sys.executable] + (["-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr",
+                                   "127.0.0.1", "--master-port", "29631", "-m", "mllm_sparse_retrieval_amd"]
+                                  if world > 1 else ["-m", "mllm_sparse_retrieval_amd"])
+        p = subprocess.run(cmd + ["search"] + common + ["--save_dir", save] + extra, stdout=subprocess.PIPE,
+                           stderr=subprocess.PIPE, env=env, timeout=600)
+        assert p.returncode == 0, p.stderr.decode()[-3000:]
+        # (without the timing line and gloo's connection banner)
+        return [x for x in p.stdout.decode().splitlines() if not x.startswith(("search:", "[Gloo]"))]
+
+    one = run(1, [], str(tmp_path / "r1"))
+    two = run(2, [], str(tmp_path / "r2"))
+    compat = run(2, ["--compat-denominator"], str(tmp_path / "r3"))
+    n = 201 * 5                                                                   # 1005 captions: odd -> one padded repeat
+    assert one[0] == str(n) and two[0] == str(n) and compat[0] == str(n + 1)
+
+    def summary(lines):
+        line = [x for x in lines if x.startswith("Sparse reps recall")][0]
+        return [float(x.split()[1].rstrip(",")) for x in line.split("r@")[1:]]
+
+    assert np.allclose(summary(one), summary(two), atol=1e-12)
+    per_rank = [x for x in two if x.startswith("Sparse recall @ 1:")][0]
+    assert per_rank.count(",") == 1                                               # two ranks' fractions
+    assert abs(summary(compat)[0] * (n + 1) - summary(one)[0] * n) <= 1 + 1e-9   # the repeat counts at most once more
+    a = sorted(open(tmp_path / "r1" / "sparse.trec").read().splitlines())
+    b = sorted(open(tmp_path / "r2" / "sparse.trec").read().splitlines())
+    assert a == b and len(a) > 9000
+    assert not os.path.exists(tmp_path / "r2" / "sparse.trec.rank0")
+
+
 # ------------------------------------------------------------------------------------------------ full-size properties
 @pytest.mark.parametrize("tile_docs,n_tiles", [(32768, 31), (0, 123)])
 def test_full_size_properties_c4(m, tmp_path, tile_docs, n_tiles):
