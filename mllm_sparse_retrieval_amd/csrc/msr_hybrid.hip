@@ -212,6 +212,151 @@ __global__ __launch_bounds__(512, 1) void dense_scores_256(const _Float16* __res
         }
 }
 
+// ---- the same 256 x 256 block with a DEEPER staging pipeline: K in sub-steps of 32 through FOUR LDS buffers of 32 KiB
+// (A: 256 rows x 64 B, B likewise), three sub-steps of LDS-DMA in flight while the fourth is consumed. The 2-buffer
+// kernel above drains its DMA with vmcnt(0) at every barrier and issues a whole K step's 8 DMAs per wave up front — at
+// 100-185 cycles of issue each that is ~1 200 cycles per wave and step during which neither wave of the SIMD feeds the
+// MFMA pipe (measured 46 % MFMA-busy cycles at 74 % L2 hit rate: not bandwidth). Here each sub-step issues 4 DMAs
+// per wave, waits with a COUNTED vmcnt (own pieces of the sub-step read next: 8 newer pieces stay in flight), uses
+// raw s_barriers (no fence, no vmcnt(0)), and runs the two waves of every SIMD in PING-PONG (see the loop):
+//     RAW: a sub-step's pieces are waited for by their issuing waves BEFORE the barrier the readers pass;
+//     WAR: a buffer is refilled after both groups' reads of it have returned (lgkmcnt(0) before the barrier in between).
+// Rows are 64 B = 4 slots of 16 B: the DMA writes LDS lane-linear (16 rows x 4 slots per instruction), so the bank
+// swizzle slot ^= (row >> 2) & 3 goes on the SOURCE address and again on the fragment reads (the four 16-lane groups
+// of a ds_read_b128 then touch 16 distinct 16-byte bank groups).
+constexpr int kGpStage = 2 * 256 * 64;  // bytes per sub-step buffer: A rows then B rows
+constexpr int kGpStages = 4;
+
+__global__ __launch_bounds__(512, 1) void dense_scores_256p(const _Float16* __restrict__ Q, const _Float16* __restrict__ P,
+                                                            uint32_t* __restrict__ out, uint32_t M, uint32_t N, uint32_t H,
+                                                            uint64_t ld, uint32_t qb_n, uint32_t db_n) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];  // 4 sub-step buffers (ONE LDS object)
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = rfl(tid >> 6);
+    const uint32_t r = lane & 31, h = lane >> 5;
+    uint32_t qb, db;
+    {   // XCD-aware patch-major order, as in dense_scores_256
+        const uint32_t n_blk = qb_n * db_n, per = (n_blk + 7u) / 8u;
+        const uint32_t xcd = blockIdx.x & 7u, slot = blockIdx.x >> 3;
+        const uint32_t t = xcd * per + slot;
+        if (slot >= per || t >= n_blk) return;
+        const uint32_t pr = t / (8u * db_n), rem = t - pr * 8u * db_n;
+        const uint32_t hp = min(8u, qb_n - 8u * pr);
+        const uint32_t pc = rem / (hp * 4u), rem2 = rem - pc * hp * 4u;
+        qb = pr * 8u + rem2 % hp;
+        db = pc * 4u + rem2 / hp;
+    }
+    const uint32_t q_blk = qb * 256, d_blk = db * 256;
+    if (d_blk >= N) {  // padding docs: keys 0
+        for (uint32_t i = tid; i < 256 * 64; i += 512) {
+            const uint32_t q = q_blk + i / 64;
+            if (q < M) reinterpret_cast<uint4*>(out + (uint64_t)q * ld + d_blk)[i % 64] = make_uint4(0, 0, 0, 0);
+        }
+        return;
+    }
+    const uint32_t wm = (wave >> 2) * 128, wn = (wave & 3) * 64;
+    float16v acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+    // DMA plan: piece c (1 KiB = 16 rows x 64 B) of an operand's sub-step; wave w issues pieces w and w + 8. Source
+    // address = (block base + k: scalar) + (row, swizzled segment: a 32-bit byte offset per lane), so that stepping k
+    // costs scalar adds only (a block's rows span 256 x H x 2 B < 4 GiB)
+    const char* const qbase = reinterpret_cast<const char*>(Q + (uint64_t)q_blk * H);
+    const char* const pbase = reinterpret_cast<const char*>(P + (uint64_t)d_blk * H);
+    uint32_t voff[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const uint32_t row = 16 * (wave + 8 * i) + (lane >> 2);
+        const uint32_t seg = (lane & 3) ^ ((row >> 2) & 3);
+        voff[i] = row * H * 2 + seg * 16;
+    }
+    typedef __attribute__((address_space(3))) void lds_void;
+    typedef const __attribute__((address_space(1))) void glb_void;
+    auto issue = [&](uint32_t stage, uint32_t k0) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            uint8_t* const da = smem + stage * kGpStage + (wave + 8 * i) * 1024;
+            __builtin_amdgcn_global_load_lds((glb_void*)(qbase + (uint64_t)k0 * 2 + voff[i]), (lds_void*)da, 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((glb_void*)(pbase + (uint64_t)k0 * 2 + voff[i]), (lds_void*)(da + 256 * 64), 16, 0, 0);
+        }
+    };
+    const uint32_t f = (r >> 2) & 3;  // swizzle of this lane's fragment rows: (wm + 32 i + r) >> 2 & 3 == (r >> 2) & 3
+    const uint32_t fa = (wm + r) * 64, fb = 256 * 64 + (wn + r) * 64;
+    const uint32_t KP = H / 32;
+    // PING-PONG: the workgroup's waves w and w + 4 share a SIMD (waves go to SIMDs cyclically); group 0 (waves 0-3) and
+    // group 1 (waves 4-7) run the same loop half a sub-step apart, so in every barrier interval one wave of each SIMD
+    // reads fragments / issues DMA while the other issues its 16 MFMAs:
+    //     interval 2p   : group 0 MEM(p)   | group 1 MFMA(p-1)
+    //     interval 2p+1 : group 0 MFMA(p)  | group 1 MEM(p)
+    // MEM(p) = 12 fragment reads of buffer p & 3, then the wave's 4 DMAs of sub-step p + 3 into buffer (p - 1) & 3 (both
+    // groups have read it: group 1 in interval 2p - 1, with lgkmcnt(0) before that interval's barrier). Before the barrier
+    // that ends an odd interval every wave waits (counted) for its own pieces of sub-step p + 1, which group 0 reads next.
+    // (Issuing the DMAs between the MFMAs instead — where one costs the issuing wave less — measured WORSE: 908 vs 953
+    // TFLOP/s; the MFMA phase got longer.)
+    const uint32_t grp = wave >> 2;
+    auto bar = []() { asm volatile("s_barrier" ::: "memory"); };
+    auto wait_landed = [&](uint32_t p_next) {  // own pieces of sub-step p_next landed; newer ones (<= 2 sub-steps) stay in flight
+        const uint32_t newer = p_next + 2 < KP ? 2u : (p_next + 1 < KP ? 1u : 0u);
+        if (newer == 2)
+            asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else if (newer == 1)
+            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    };
+    issue(0, 0);
+    if (KP > 1) issue(1, 32);
+    if (KP > 2) issue(2, 64);
+    wait_landed(0);
+    bar();
+    if (grp) bar();  // group 1 starts half a sub-step later
+    for (uint32_t p = 0; p < KP; ++p) {
+        // ---- MEM(p)
+        const uint8_t* const st = smem + (p & 3) * kGpStage;
+        half8 a[2][4], b[2][2];
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            const uint32_t slot = ((2 * kk + h) ^ f) * 16;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) a[kk][i] = *reinterpret_cast<const half8*>(st + fa + i * 32 * 64 + slot);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) b[kk][j] = *reinterpret_cast<const half8*>(st + fb + j * 32 * 64 + slot);
+        }
+        if (p + 3 < KP) issue((p + 3) & 3, (p + 3) * 32);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the fragments are in registers: the buffer may be refilled
+        if (grp) wait_landed(p + 1);                        // (group 1's MEM is the odd interval)
+        bar();
+        // ---- MFMA(p)
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[kk][i], b[kk][j], acc[i][j], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+        if (!grp) wait_landed(p + 1);                       // (group 0's MFMA is the odd interval)
+        bar();
+    }
+    if (!grp) bar();  // every wave has passed the same number of barriers
+    // C/D map of the 32x32 shapes: column = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const uint32_t d = d_blk + wn + 32 * j + r;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const uint32_t q = q_blk + wm + 32 * i + (e & 3) + 8 * (e >> 2) + 4 * h;
+                if (q < M) out[(uint64_t)q * ld + d] = d < N ? f32_to_key(acc[i][j][e]) : 0u;
+            }
+        }
+}
+
 }  // namespace msr
 
 struct msr_dense {
@@ -291,6 +436,8 @@ static int launch_dense_gemm(msr_dense* dx, const _Float16* P, const _Float16* d
     if (big && !dx->lds_attr_set) {  // 128 KiB of dynamic LDS needs the opt-in (per device: kept in the handle)
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(dense_scores_256),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, 2 * kG2Stage));
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(dense_scores_256p),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, kGpStages * kGpStage));
         dx->lds_attr_set = true;
     }
     const uint64_t blk = big ? 256 : 128;
@@ -298,7 +445,12 @@ static int launch_dense_gemm(msr_dense* dx, const _Float16* P, const _Float16* d
         const uint64_t nd = std::min<uint64_t>(n_cover - d0, blk * kMaxGridY);
         const uint32_t n_left = dx->n > d0 ? (uint32_t)std::min<uint64_t>(dx->n - d0, 0xFFFFFFFFull) : 0u;
         static const bool no_patch = getenv("MSR_GEMM_NO_PATCH") != nullptr;  // diagnostic: the plain 2-D grid
-        if (big && !no_patch) {
+        static const bool no_pipe = getenv("MSR_GEMM_NO_PIPE") != nullptr;    // diagnostic: the 2-buffer kernel
+        if (big && !no_patch && !no_pipe) {
+            const uint32_t qb_n = qn_pad / 256, db_n = (uint32_t)(nd / 256);
+            hipLaunchKernelGGL(dense_scores_256p, dim3((qb_n * db_n + 7) / 8 * 8), dim3(512), kGpStages * kGpStage, st, d_Q,
+                               P + d0 * dx->h, d_S + d0, qn, n_left, dx->h, ld, qb_n, db_n);
+        } else if (big && !no_patch) {
             const uint32_t qb_n = qn_pad / 256, db_n = (uint32_t)(nd / 256);
             hipLaunchKernelGGL(dense_scores_256, dim3((qb_n * db_n + 7) / 8 * 8), dim3(512), 2 * kG2Stage, st, d_Q,
                                P + d0 * dx->h, d_S + d0, qn, n_left, dx->h, ld, qb_n, db_n);
