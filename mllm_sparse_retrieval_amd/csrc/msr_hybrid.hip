@@ -294,8 +294,12 @@ __global__ __launch_bounds__(512, 1) void dense_scores_256p(const _Float16* __re
     // MEM(p) = 12 fragment reads of buffer p & 3, then the wave's 4 DMAs of sub-step p + 3 into buffer (p - 1) & 3 (both
     // groups have read it: group 1 in interval 2p - 1, with lgkmcnt(0) before that interval's barrier). Before the barrier
     // that ends an odd interval every wave waits (counted) for its own pieces of sub-step p + 1, which group 0 reads next.
-    // (Issuing the DMAs between the MFMAs instead — where one costs the issuing wave less — measured WORSE: 908 vs 953
-    // TFLOP/s; the MFMA phase got longer.)
+    // Measured with s_memtime laps (one block, 128 sub-steps, cycles per sub-step and wave): MEM 780 (fragment reads +
+    // DMA issue + lgkmcnt), counted vmcnt wait 300, MFMA issue 575, barriers 360 — 2 020 per sub-step for 1 024 cycles of
+    // MFMA per SIMD = the 52 % MFMA-busy the counters show, at a clock that sags to ~1.85 GHz under this load (2.55 GHz in
+    // the integer kernels). Moving 1, 2 or all 4 DMAs between the MFMAs shortens MEM by < 10 % and lengthens MFMA (908
+    // vs 949 TFLOP/s for all 4); without s_setprio 840. What is left is the fragment-read phase itself and the DMA
+    // latency under load (~4 000 cycles: three sub-steps in flight do not quite cover it).
     const uint32_t grp = wave >> 2;
     auto bar = []() { asm volatile("s_barrier" ::: "memory"); };
     auto wait_landed = [&](uint32_t p_next) {  // own pieces of sub-step p_next landed; newer ones (<= 2 sub-steps) stay in flight
