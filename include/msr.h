@@ -77,7 +77,9 @@ int msr_index_build(const char* jsonl_dir, const char* out_path, int threads, ui
 
 /* Process-wide build options (set before building; not thread-safe):
  *   "dense_min_density" (default 0.4): a term with df >= density * n_docs is stored in the doc-major dense head
- *   "dense_max_terms"   (default 16, at most 32; 0 disables the dense head) */
+ *   "dense_max_terms"   (default 16, at most 32; 0 disables the dense head)
+ *   "tie_order"         (default 0: doc ordinals = rank of the doc-id string, so a score tie goes to the bytewise lower
+ *                        doc id, contract T1; 1: ordinals = input order, a tie goes to the doc indexed first) */
 int msr_set_build_option(const char* key, double value);
 
 /* Same index from a doc-major CSR already in memory (used by the synthetic encode step and the benchmark).

@@ -277,8 +277,12 @@ int build_from_csr(const char* out_path, uint64_t n_docs, uint32_t n_terms, cons
     }
     std::vector<uint32_t> row_of_ord(n_docs);
     std::iota(row_of_ord.begin(), row_of_ord.end(), 0u);
-    std::stable_sort(row_of_ord.begin(), row_of_ord.end(),
-                     [&](uint32_t a, uint32_t b) { return strcmp(idp[a], idp[b]) < 0; });
+    // (build option "tie_order" = 1 keeps the INPUT order instead: a score tie then goes to the doc that was indexed
+    // first — what Lucene's internal doc numbers give under a single indexing thread — so that an integrator can check
+    // either tie rule against a real pyserini run; contract T1 is unpinned)
+    if (!build_options().tie_input_order)
+        std::stable_sort(row_of_ord.begin(), row_of_ord.end(),
+                         [&](uint32_t a, uint32_t b) { return strcmp(idp[a], idp[b]) < 0; });
 
     const uint32_t n_tiles = (uint32_t)((n_docs + tile_docs - 1) / tile_docs);
     const uint64_t stride = (uint64_t)n_terms + 1;
@@ -1163,6 +1167,8 @@ int msr_set_build_option(const char* key, double value) {
         o.dense_min_density = value;
     } else if (strcmp(key, "dense_max_terms") == 0 && value >= 0 && value <= kMaxDense) {
         o.dense_max_terms = (uint32_t)value;
+    } else if (strcmp(key, "tie_order") == 0 && (value == 0 || value == 1)) {
+        o.tie_input_order = value == 1;
     } else {
         set_error("unknown build option '%s' or value %g out of range", key, value);
         return MSR_E_INVAL;

@@ -152,6 +152,7 @@ void term_bounds(const HostIndex& hx, int G, std::vector<uint32_t>& bounds);
 struct BuildOptions {
     double dense_min_density = 0.4;  // a term is stored in the dense head when df >= this * n_docs
     uint32_t dense_max_terms = 16;   // at most this many (<= kMaxDense); 0 disables the dense head
+    bool tie_input_order = false;    // doc ordinals = input order instead of doc-id string order (tie rule switch)
 };
 BuildOptions& build_options();
 

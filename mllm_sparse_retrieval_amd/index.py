@@ -35,7 +35,8 @@ def auto_tile_docs(n_docs):
 
 
 def set_build_option(key, value):
-    """'dense_min_density' (default 0.4) / 'dense_max_terms' (default 16, 0 = no dense head) for later builds."""
+    """'dense_min_density' (default 0.4) / 'dense_max_terms' (default 16, 0 = no dense head) / 'tie_order' (0: ties go
+    to the lower doc-id string, contract T1; 1: to the doc that came first in the input) for later builds."""
     check(lib().msr_set_build_option(key.encode(), float(value)))
 
 

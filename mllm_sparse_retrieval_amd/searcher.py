@@ -50,12 +50,22 @@ def tokenize_queries(queries):
 
 
 class LuceneImpactSearcher:
-    def __init__(self, index_dir, query_encoder=None, min_idf=0, device=0):
+    """PARITY UNPINNED for the scorer: T1-T5 below restate pyserini / Lucene impact search as recalled (SURVEY.md §8a
+    A3), the reference pins none of it and Lucene cannot run here. The two points most likely to differ from a real
+    pyserini run are explicit switches, so an integrator can flip them when checking:
+      drop_df_eq_n  None: follow min_idf (terms present in EVERY doc are dropped while min_idf >= 0, contract T3);
+                    True / False: force the df == N filter on / off.
+      tie rule      a build-time property of the index: `set_build_option("tie_order", 1)` before building numbers the
+                    docs in input order (a score tie goes to the doc indexed first, like Lucene's internal doc ids
+                    under one indexing thread) instead of doc-id string order (contract T1, the default)."""
+
+    def __init__(self, index_dir, query_encoder=None, min_idf=0, device=0, drop_df_eq_n=None):
         if query_encoder is not None:
             raise NotImplementedError("only query_encoder=None (token-frequency queries) is supported, as in the "
                                       "reference (src/search.py:273)")
         self.index = SparseIndex(index_dir, device=device)
         self.min_idf = min_idf
+        self.drop_df_eq_n = drop_df_eq_n
         self.num_docs = self.index.n_docs
 
     def set_analyzer(self, analyzer):
@@ -82,9 +92,11 @@ class LuceneImpactSearcher:
             with np.errstate(divide="ignore"):
                 idf = np.log(self.index.n_docs / np.maximum(df, 1e-300))
             ws = np.where((df > 0) & (idf > self.min_idf), ws, 0).astype(np.int32)
-            ords, scores, _, n = self.index.search_csr(q_ptr, term_ids, ws, k, drop_df_eq_n=True)
+            drop = True if self.drop_df_eq_n is None else bool(self.drop_df_eq_n)
+            ords, scores, _, n = self.index.search_csr(q_ptr, term_ids, ws, k, drop_df_eq_n=drop)
         else:
-            ords, scores, _, n = self.index.search_text(queries, k, drop_df_eq_n=self.min_idf >= 0)
+            drop = self.min_idf >= 0 if self.drop_df_eq_n is None else bool(self.drop_df_eq_n)
+            ords, scores, _, n = self.index.search_text(queries, k, drop_df_eq_n=drop)
         out = {}
         table = self.index.docid_table() if len(qids) * k > 64 else None
         score_rows = scores.tolist()

@@ -126,3 +126,22 @@ def test_synth_is_deterministic_and_shaped(m):
     rows = t.reshape(500, 32)
     assert all(len(set(r)) == 32 for r in rows) and (np.diff(rows, axis=1) > 0).all()
     assert (t == 0).mean() > (t == 500).mean()  # Zipf: low ranks dominate
+
+
+def test_tie_order_switch_numbers_docs_in_input_order(tmp_path):
+    """Build option tie_order = 1: doc ordinals follow the INPUT order (a score tie goes to the doc indexed first)
+    instead of the doc-id string order of contract T1 — the switch an integrator flips when checking against pyserini."""
+    import mllm_sparse_retrieval_amd as m
+
+    ids = ["10", "9", "100", "2"]
+    dp = np.arange(5, dtype=np.uint64)
+    dt = np.zeros(4, dtype=np.uint32)
+    dw = np.full(4, 3, dtype=np.uint32)
+    a = m.build_index_from_csr(str(tmp_path / "a.idx"), dp, dt, dw, 2, doc_ids=ids, tile_docs=4096)
+    m.set_build_option("tie_order", 1)
+    try:
+        b = m.build_index_from_csr(str(tmp_path / "b.idx"), dp, dt, dw, 2, doc_ids=ids, tile_docs=4096)
+    finally:
+        m.set_build_option("tie_order", 0)
+    assert helpers.read_index_file(a)["docs"] == sorted(ids, key=lambda s: s.encode())   # "10" < "100" < "2" < "9"
+    assert helpers.read_index_file(b)["docs"] == ids
