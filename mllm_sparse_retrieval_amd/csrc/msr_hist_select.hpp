@@ -14,8 +14,7 @@
 // ties) is split again, linearly in the composite, until it does not: at most 5 levels, one in practice.
 #pragma once
 
-#include "msr_select.hpp"
-
+// (included by msr_select.hpp, after its cross-lane helpers and before tile_select, which uses it for large k)
 namespace msr {
 
 constexpr int kHistBins = 1024;

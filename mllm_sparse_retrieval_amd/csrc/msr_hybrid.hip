@@ -2,7 +2,6 @@
 // the GPU (fuse_tiles), the log1p-relu top-k sparsifier (sparsify_keys), and their C-ABI entry points. Selection and
 // list merging reuse the search path's kernels (launch_select / launch_merge, msr_device.hip).
 #include "msr_accumulate.hpp"
-#include "msr_hist_select.hpp"
 
 using namespace msr;
 

@@ -163,6 +163,12 @@ struct TileLds {
 };
 
 
+}  // namespace msr
+
+#include "msr_hist_select.hpp"
+
+namespace msr {
+
 // Exact top-k of one accumulator tile held in LDS (shared by score_tiles and select_tiles).
 // Thread `tid` owns vec r*NT + tid of the accumulators in round r (conflict-free ds_read_b128); the accumulators are
 // re-read from LDS in every pass instead of being held in registers. Writes k keys best-first (0 = empty slot).
@@ -253,7 +259,35 @@ __device__ __forceinline__ void tile_select(const uint4* a4, uint64_t* cand, uin
     stamp(5);  // candidate collection
     uint32_t n_cand = ss.n_cand;
 
-    if (n_cand > CAND) {
+    if (TILE_DOCS <= 8192 && CAND >= 2 * kHistCand && n_cand > CAND) {
+        // ---- k in the hundreds (the reference's default depth is 1000, src/arguments.py:59), or mass ties: ONE
+        // histogram pass finds the composite threshold of the k best (hist_threshold, msr_hist_select.hpp); the
+        // accumulators at or above it are exactly min(k, #positive) <= CAND keys. (Instances with a 512-key candidate
+        // buffer or tiles above 8192 docs keep the byte-wise radix passes below.)
+        if constexpr (TILE_DOCS <= 8192 && CAND >= 2 * kHistCand) {
+            static_assert(TileLds<TILE_DOCS, NT, CAND>::kTmax >= (int)sizeof(HistScratch), "selection scratch");
+            uint32_t* const hist = reinterpret_cast<uint32_t*>(cand);
+            HistScratch& hs = *reinterpret_cast<HistScratch*>(tmax);  // (tmax is dead since tau0 was published)
+            const HistResult hr = hist_threshold<TILE_DOCS, NT>(
+                [&](int r) { return r < rounds ? a4[r * NT + tid] : make_uint4(0, 0, 0, 0); }, (uint32_t)k, hist,
+                cand + kHistBins / 2, hs, tid, [](uint32_t key, uint32_t lo) { return (float)(key - lo); });
+            if (tid == 0) ss.n_cand = 0;
+            __syncthreads();  // the histogram / candidate area becomes the key buffer
+            for (int r = 0; r < rounds; ++r) {
+                const uint4 x = a4[r * NT + tid];
+                const uint32_t sc4[4] = {x.x, x.y, x.z, x.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const uint32_t local = 4 * (r * NT + tid) + e;
+                    if (sc4[e] != 0 && (((uint64_t)sc4[e] << 13) | (uint64_t)(TILE_DOCS - 1 - local)) >= hr.T)
+                        cand[atomicAdd(&ss.n_cand, 1u)] =
+                            ((uint64_t)sc4[e] << 32) | (uint64_t)(0xFFFFFFFFu - (uint32_t)(doc0 + local));
+                }
+            }
+            __syncthreads();
+            n_cand = min(ss.n_cand, (uint32_t)CAND);  // == min(k, #positive) <= CAND by construction
+        }
+    } else if (n_cand > CAND) {
         // ---- fallback (mass ties, or k in the hundreds): exact selection by radix passes over the score.
         //   1. tau = k-th largest SCORE of the tile, one BYTE per pass, most significant first: a 256-bin LDS histogram
         //      of the accumulators that match the bytes fixed so far, then every wave finds the bin that holds the
