@@ -782,28 +782,38 @@ def run_c5(args, ranks, m):
     wall = time.perf_counter() - t0
     kern = sum(ms.values())
     flops = 2.0 * nq * n * h
+    fused = ms["dense_select"] == 0 and ms["fusion"] == 0  # single-tile index: hybrid_tiles does everything but the GEMM
+    kernel_ms = ({"hybrid_tiles": round(ms["sparse"], 3), "dense_gemm": round(ms["dense_gemm"], 3)} if fused
+                 else {k2: round(v, 3) for k2, v in ms.items()})
     out = {"workload": f"hybrid: {n} docs x (128 nnz + {h}-d fp16), {nq} queries x (120 nnz + {h}-d), depth {depth} -> "
                        f"fused top-{k}, alpha {alpha}",
            "value": round(nq / (kern * 1e-3), 1), "unit": "queries/s (kernel time, inputs resident)",
            "host_inclusive_queries_per_s": round(nq / wall, 1),
-           "kernel_ms": {k2: round(v, 3) for k2, v in ms.items()},
+           "kernel_ms": kernel_ms,
+           "pipeline": ("dense_scores_256p (fp16 MFMA GEMM on the ordinal-ordered passage matrix, query chunks of ~160 MB "
+                        "of score rows) -> hybrid_tiles (one workgroup per query: sparse scores in LDS, both depth-"
+                        f"{depth} memberships by one histogram pass, min-max fusion, top-{k})") if fused else
+                       "list-based: score_tiles + dense GEMM + select_tiles + fuse_tiles + merges (multi-tile index)",
            "dense_tflops": round(flops / (ms["dense_gemm"] * 1e-3) / 1e12, 1) if ms["dense_gemm"] > 0 else None,
            "dtype": "f16 in / f32 accumulate (dense), u32 (sparse), f32 (fusion)"}
-    # roofline per stage: the GEMM against the dense fp16 MFMA peak; selection / fusion against HBM with the bytes
-    # they have to move (counter-backed traffic where profiled)
+    # roofline per stage: the GEMM against the dense fp16 MFMA peak; the integer / selection kernels against the
+    # ceilings they can run into (counter-backed where profiled)
     rl = {}
     if ms["dense_gemm"] > 0:
         tf = flops / (ms["dense_gemm"] * 1e-3) / 1e12
         rl["dense_gemm"] = {"bound": "mfma", "achieved": round(tf, 1), "peak": MFMA_F16_PEAK_TF, "unit": "TFLOP/s",
                             "frac": round(tf / MFMA_F16_PEAK_TF, 4), "kernel_ms": round(ms["dense_gemm"], 4),
                             **binding_fractions(counters("c5_hybrid", "dense_scores"), ms["dense_gemm"])}
-    for stage, kre in (("dense_select", "select_tiles|dense_select"), ("fusion", "fuse_tiles"), ("sparse", "score_tiles")):
-        if ms.get(stage, 0) > 0:
-            fr = binding_fractions(counters("c5_hybrid", kre), ms[stage])
-            cands = {b: fr.get(key) for b, key in (("hbm", "hbm_frac"), ("l2", "l2_frac"), ("valu", "valu_busy"))
-                     if fr.get(key) is not None}
+    stages = ((("hybrid_tiles", "hybrid_tiles", "sparse"),) if fused else
+              (("dense_select", "select_tiles", "dense_select"), ("fusion", "fuse_tiles", "fusion"),
+               ("sparse", "score_tiles", "sparse")))
+    for stage, kre, key in stages:
+        if ms.get(key, 0) > 0:
+            fr = binding_fractions(counters("c5_hybrid", kre), ms[key])
+            cands = {b: fr.get(k3) for b, k3 in (("hbm", "hbm_frac"), ("l2", "l2_frac"), ("valu", "valu_busy"))
+                     if fr.get(k3) is not None}
             bound = max(cands, key=cands.get) if cands else None
-            rl[stage] = {"bound": bound, "frac": cands.get(bound) if bound else None, "kernel_ms": round(ms[stage], 4), **fr}
+            rl[stage] = {"bound": bound, "frac": cands.get(bound) if bound else None, "kernel_ms": round(ms[key], 4), **fr}
     out["roofline"] = rl
     if not args.no_cpu:
         phase("c5 parity sample vs the oracle pipeline")

@@ -210,7 +210,11 @@ void msr_dense_close(msr_dense* dx);
 /* ---- hybrid search on the GPU: sparse top-`depth` + dense top-`depth` + the reference's min-max fusion
  * (fuse, src/hybrid.py:32-53, weights [alpha, 1-alpha] src/search.py:459) + top-k, without leaving HBM in between.
  * row2ord[r] = sparse doc ordinal of dense row r; self_ord[q] (nullable) = ordinal removed from query q's lists
- * (remove_query, src/search.py:72-74) or -1. ms (nullable) = {sparse, dense GEMM, dense select, fusion} kernel ms. */
+ * (remove_query, src/search.py:72-74) or -1. ms (nullable) = {sparse, dense GEMM, dense select, fusion} kernel ms.
+ * Single-tile indexes (n_docs <= 8192) with k <= 64 take the fused path: the GEMM runs on the passage rows permuted into
+ * ordinal order, and ONE kernel per query does sparse scoring + both depth selections + fusion + top-k; ms is then
+ * {that kernel, dense GEMM, 0, 0}, and a tie in the DENSE score at the depth boundary goes to the lower doc ordinal
+ * (the list-based path: to the lower row index). row2ord must be a permutation of the ordinals. */
 int msr_hybrid_search(msr_index* ix, msr_dense* dx, const int64_t* q_ptr, const int32_t* q_term, const int32_t* q_w,
                       const uint16_t* q_fp16, int nq, int depth, int k, float alpha, uint32_t flags,
                       const uint32_t* row2ord, const int32_t* self_ord, uint32_t* out_ord, float* out_score, int32_t* out_n,

@@ -1015,9 +1015,9 @@ __global__ __launch_bounds__(NT, MIN_WAVES) void hybrid_tiles(const ScoreArgs a,
     __syncthreads();
     uint64_t T_s = ds.T[0], T_d = ds.T[1];
     // ---- rare: a side without spread, or a bin with more than kHistCand elements (mass ties): the general selection
-    if (n_s != 0 && !fast_s)  // (uniform)
+    if (__builtin_expect(n_s != 0 && !fast_s, 0))  // (uniform, rare)
         T_s = threshold_general<TILE_DOCS, NT>(acc, rounds, ndocs, h.depth, false, hist, cand + kHistBins / 2, &hs, tid);
-    if (!fast_d)
+    if (__builtin_expect(!fast_d, 0))
         T_d = threshold_general<TILE_DOCS, NT>(h.dkeys + (uint64_t)blockIdx.x * h.ld, rounds, ndocs, h.depth, true, hist,
                                                cand + kHistBins / 2, &hs, tid);
     stamp(1);
@@ -1033,9 +1033,12 @@ __global__ __launch_bounds__(NT, MIN_WAVES) void hybrid_tiles(const ScoreArgs a,
     // fused scores lie in [min(w,0) sums, max(w,0) sums]
     const float f_lo = fminf(h.w_dense, 0.f) + fminf(h.w_sparse, 0.f), f_hi = fmaxf(h.w_dense, 0.f) + fmaxf(h.w_sparse, 0.f);
     const float sc_f = ((float)kHistBins - 0.5f) / fmaxf(f_hi - f_lo, 1e-30f);
-    // (x - min) * (w / den) instead of w * ((x - min) / den): one multiplication per term, 1-2 ulp from the reference's
-    // order of operations, far inside the 1e-5 the fused scores are held to
-    const float cd = h.w_dense / dden, cs = h.w_sparse / sden;
+    // w * ((x - min) / den) with the division as a multiplication by 1 / den (<= 1 ulp from the quotient, far inside the
+    // 1e-5 the fused scores are held to) — but EXACTLY 1 at x = max, as the quotient is: with alpha = 0.5 the best
+    // dense-only doc and the best sparse-only doc tie at exactly 0.5 in the reference, and that tie must stay a tie
+    // (it is then broken like every other: lower ordinal first)
+    const float inv_dden = 1.0f / dden, inv_sden = 1.0f / sden;
+    const bool spread_d = dmax > dmin, spread_s = smax > smin;  // (max == min: every quotient is 0 / 1e-9 = 0)
     for (int i = tid; i < kHistBins / 4; i += NT) reinterpret_cast<uint4*>(hist)[i] = make_uint4(0, 0, 0, 0);
     if (tid < 64) ss.cnt[tid] = 0;
     if (tid == 0) {
@@ -1044,13 +1047,13 @@ __global__ __launch_bounds__(NT, MIN_WAVES) void hybrid_tiles(const ScoreArgs a,
         ss.smax = 0;
     }
     __syncthreads();  // histogram zeroed (the candidate lists that lived there are dead)
-    uint32_t fkeys[E];
     uint32_t n_mem = 0;
 #pragma unroll
     for (int r = 0; r < R; ++r)
         if (r < rounds) {
             const uint4 x = a4[r * NT + tid];
             const uint32_t s4[4] = {x.x, x.y, x.z, x.w};
+            uint32_t fk[4];
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const uint32_t local = 4u * ((uint32_t)r * NT + tid) + (uint32_t)e;
@@ -1059,10 +1062,10 @@ __global__ __launch_bounds__(NT, MIN_WAVES) void hybrid_tiles(const ScoreArgs a,
                 const bool in_d = d > td_f || (d == td_f && inv >= td_inv);
                 const bool in_s = s4[e] != 0 && (s4[e] > ts_key || (s4[e] == ts_key && inv >= ts_inv));
                 float f = 0.f;  // the reference adds the dense term first (runs = [dense, sparse], src/search.py:459)
-                if (in_d) f += (d - dmin) * cd;
-                if (in_s) f += ((float)s4[e] - smin) * cs;
+                if (in_d) f += h.w_dense * ((d == dmax && spread_d) ? 1.0f : (d - dmin) * inv_dden);
+                if (in_s) f += h.w_sparse * ((s4[e] == smax_u && spread_s) ? 1.0f : ((float)s4[e] - smin) * inv_sden);
                 const bool member = (in_d || in_s) && local != self;
-                fkeys[4 * r + e] = member ? f32_to_key(f) : 0u;
+                fk[e] = member ? f32_to_key(f) : 0u;
                 const uint32_t fb = (uint32_t)((f - f_lo) * sc_f);
                 bins[4 * r + e] = member ? fb : 0xFFFFFFFFu;  // (the selection bins are dead: reuse the registers)
                 if (member) {
@@ -1070,10 +1073,10 @@ __global__ __launch_bounds__(NT, MIN_WAVES) void hybrid_tiles(const ScoreArgs a,
                     ++n_mem;
                 }
             }
-            a4[r * NT + tid] = make_uint4(fkeys[4 * r], fkeys[4 * r + 1], fkeys[4 * r + 2], fkeys[4 * r + 3]);
+            a4[r * NT + tid] = make_uint4(fk[0], fk[1], fk[2], fk[3]);
         } else {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) fkeys[4 * r + e] = 0, bins[4 * r + e] = 0xFFFFFFFFu;
+            for (int e = 0; e < 4; ++e) bins[4 * r + e] = 0xFFFFFFFFu;
         }
     n_mem = wave_sum_u32(n_mem);
     if (lane == 0) atomicAdd(&ds.red[5], n_mem);
@@ -1122,16 +1125,30 @@ __global__ __launch_bounds__(NT, MIN_WAVES) void hybrid_tiles(const ScoreArgs a,
     }
     __syncthreads();
     const uint32_t n_top = need_f ? ds.fabove + ds.fcnt : 0u;  // members at or above the k-th best's bin
-    if (n_top <= 64) {
+    if (__builtin_expect(n_top <= 64, 1)) {
         // the usual case: a handful of members; one wave ranks them and writes the result rows
         const uint32_t fbin = ds.fbin;
         uint64_t* const top = reinterpret_cast<uint64_t*>(tmax);  // 64 keys
+        {   // (the fused keys are re-read from the tile this thread wrote them to: nothing but the bins is kept in
+            // registers across the scan)
+            uint32_t hit = 0;
 #pragma unroll
-        for (int j = 0; j < E; ++j)
-            if (need_f && bins[j] != 0xFFFFFFFFu && bins[j] >= fbin) {
-                const uint32_t local = 4u * ((uint32_t)(j / 4) * NT + tid) + (uint32_t)(j % 4);
-                top[atomicAdd(&ds.fn, 1u)] = ((uint64_t)fkeys[j] << 32) | (uint64_t)(0xFFFFFFFFu - local);
+            for (int j = 0; j < E; ++j) hit |= (uint32_t)(bins[j] != 0xFFFFFFFFu && bins[j] >= fbin) << j;
+            if (need_f && hit) {
+#pragma unroll
+                for (int r = 0; r < R; ++r)
+                    if (r < rounds && (hit >> (4 * r) & 15u)) {
+                        const uint4 x = a4[r * NT + tid];
+                        const uint32_t k4[4] = {x.x, x.y, x.z, x.w};
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            if (hit >> (4 * r + e) & 1u) {
+                                const uint32_t local = 4u * ((uint32_t)r * NT + tid) + (uint32_t)e;
+                                top[atomicAdd(&ds.fn, 1u)] = ((uint64_t)k4[e] << 32) | (uint64_t)(0xFFFFFFFFu - local);
+                            }
+                    }
             }
+        }
         __syncthreads();
         if (tid < 64) {
             const uint64_t me = tid < n_top ? top[tid] : 0ull;
