@@ -328,7 +328,20 @@ def binding_fractions(c, kernel_ms):
         if "TCC_MISS_sum" in c:
             out["l2_hit_rate"] = round(c["TCC_HIT_sum"] / max(c["TCC_HIT_sum"] + c["TCC_MISS_sum"], 1.0), 4)
     if "SQ_ACTIVE_INST_VALU" in c and "GRBM_GUI_ACTIVE" in c:
-        cycles = c["GRBM_GUI_ACTIVE"] / N_XCDS  # GRBM_GUI_ACTIVE is summed over the 8 XCDs
+        # busy quad-cycles of the VALU (a property of the work done) against the SIMD-cycles of the LIVE kernel time at
+        # the clock the counter pass saw (GRBM_GUI_ACTIVE is summed over the 8 XCDs; a counter set can slow a kernel
+        # down, so the clock comes from that pass's own kernel duration)
+        cycles_pass = c["GRBM_GUI_ACTIVE"] / N_XCDS
+        dur_pass = c.get("duration_ns_sq2")
+        if dur_pass:
+            # (GRBM_GUI_ACTIVE over-counts for a dispatch that follows another kernel closely — hybrid_tiles after the
+            # GEMM reads 7 "GHz" — so the clock is capped at the 2.4 GHz peak engine clock: busy fractions can only
+            # come out LOWER than the truth that way, never higher)
+            clock_ghz = min(cycles_pass / dur_pass, 2.4)
+            cycles = t * clock_ghz * 1e9
+            out["clock_ghz"] = round(clock_ghz, 3)
+        else:
+            cycles = cycles_pass
         out["valu_busy"] = round(4.0 * c["SQ_ACTIVE_INST_VALU"] / max(cycles * N_SIMDS, 1.0), 4)
         if "SQ_ACTIVE_INST_LDS" in c:
             out["lds_issue_busy"] = round(4.0 * c["SQ_ACTIVE_INST_LDS"] / max(cycles * N_SIMDS, 1.0), 4)

@@ -42,6 +42,11 @@ for suffix in ("fetch", "l2", "sq", "sq2"):
     for f in newest(f"{prefix}_{suffix}/*/*_counter_collection.csv"):
         for r in csv.DictReader(open(f)):
             kern[short(r["Kernel_Name"])][r["Counter_Name"]] += float(r["Counter_Value"])
+    # kernel time under THIS pass's counter set (some sets slow a kernel down: cycle counters of a pass must be read
+    # against that pass's own duration, e.g. clock = GRBM_GUI_ACTIVE / 8 / duration_ns_sq2)
+    for f in newest(f"{prefix}_{suffix}/*/*_kernel_trace.csv"):
+        for r in csv.DictReader(open(f)):
+            kern[short(r["Kernel_Name"])]["duration_ns_" + suffix] += int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
 try:
     doc = json.load(open(out_path))
 except Exception:
