@@ -265,4 +265,150 @@ __device__ __forceinline__ void accumulate_tile(const ScoreArgs& a, const uint32
     __syncthreads();  // accumulation complete; the staging view of the union is dead from here on
 }
 
+
+// ------------------------------------------------------------------------------------------------ light queries
+// The same accumulation for batches whose queries hold at most 64 sparse (non dense-head) terms — the shape of the
+// headline workload (Flickr30K captions: 8-15 terms, a handful of one-chunk segments per tile). The general path above
+// spends most of such a workgroup's life on machinery sized for 256-term rounds: segment table in LDS, a cross-wave
+// scan, two barriers, a 64-lane binary search per wave — and only then requests the first postings, whose L2 round trip
+// is fully exposed. Here EVERY wave keeps the query's segment table in registers (lane j = term j: redundant loads,
+// no LDS, no barrier), scans the chunk counts with one DPP scan, resolves its own chunks (chunk c -> wave c % NW) with
+// a ballot + four v_readlane each, and has its first UL chunk loads IN FLIGHT before the accumulators are initialised,
+// so the posting latency hides behind the dense-head / zeroing phase. Two barriers in all (accumulators initialised;
+// accumulation complete).
+template <int TILE_DOCS, int NT, class Stamp>
+__device__ __forceinline__ void accumulate_tile_light(const ScoreArgs& a, const uint32_t q, const uint32_t tile_l,
+                                                      const int rounds, uint8_t* const lds, SelectScratch& ss,
+                                                      Stamp stamp, const uint32_t tid) {
+    constexpr int NW = NT / 64;
+    constexpr int UL = 4;  // chunk loads per wave and batch
+    static_assert(TILE_DOCS % (4 * NT) == 0, "tile must be a multiple of 4*NT");
+    uint32_t* const acc = reinterpret_cast<uint32_t*>(lds);
+    const uint32_t lane = tid & 63;
+    const uint32_t lane16 = lane * 16u;
+    const uint32_t wave = rfl(tid >> 6);
+    uint4* const a4 = reinterpret_cast<uint4*>(acc);
+
+    const uint4 meta = a.q_meta[q];  // {first term, end term, dense-head pair mask}
+    const uint32_t qb = meta.x, cnt = min(meta.y - meta.x, 64u);  // (the host picks this path only when every query fits)
+    const uint32_t* seg_row = a.seg_ptr + (uint64_t)tile_l * (a.n_terms + 1);
+    const uint32_t tile_first = seg_row[0];
+    const char* const post_base = reinterpret_cast<const char*>(a.postings) + (uint64_t)(tile_first - a.vec_base) * 16u;
+    const bool has = lane < cnt;
+    uint32_t s_t = 0, s_w = 0;
+    if (has) {
+        s_t = a.q_term[qb + lane];
+        s_w = a.q_w[qb + lane];
+    }
+    // chunk data of this wave's first UL chunks: requested inside the init phase, consumed after it
+    uint4 v[UL];
+    uint32_t n16[UL], wq[UL];
+    uint32_t s_start = 0, s_len = 0, pref = 0, count_w = 0;
+    auto resolve_and_load = [&](uint32_t u0) {  // chunks u0 .. u0+UL-1 of this wave (chunk index c = wave + u * NW)
+#pragma unroll
+        for (int u = 0; u < UL; ++u) {
+            n16[u] = 0;
+            v[u] = make_uint4(0, 0, 0, 0);
+            if (u0 + (uint32_t)u < count_w) {  // wave-uniform: most waves of a light query hold one or two chunks
+                const uint32_t c = wave + (u0 + (uint32_t)u) * NW;
+                // pref is non-decreasing over the lanes: the lanes with pref <= c are a prefix, its last lane owns chunk c
+                const uint32_t lo = (uint32_t)__popcll(__ballot(has && pref <= c)) - 1u;
+                const uint32_t voff = (c - rdl(pref, lo)) << 6;  // vecs into the segment
+                const uint32_t b16 = (rdl(s_start, lo) + voff) << 4;
+                n16[u] = min(64u, rdl(s_len, lo) - voff) << 4;
+                wq[u] = rdl(s_w, lo);
+                // (the chunk's END in the resource's size word: lanes past it read zeros without a request)
+                v[u] = buf_load16(make_rsrc(post_base, b16 + n16[u]), lane16, b16);
+            }
+        }
+    };
+    auto add_loaded = [&]() {
+#pragma unroll
+        for (int u = 0; u < UL; ++u)
+            if (n16[u] != 0 && lane16 < n16[u]) {  // (n16 is wave-uniform: an idle slot costs one scalar compare)
+                const uint32_t p[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) atomicAdd(&acc[p[e] & 0xFFFFu], __umul24(p[e] >> 16, wq[u]));
+            }
+    };
+    auto prefetch = [&]() {  // segment table, chunk scan, first chunk loads: all per wave, in registers
+        if (has) {
+            const uint32_t s0 = seg_row[s_t], s1 = seg_row[s_t + 1];
+            s_start = s0 - tile_first;
+            s_len = s1 - s0;
+        }
+        const uint32_t nch = (s_len + (uint32_t)kChunkVecs - 1) / (uint32_t)kChunkVecs;
+        const uint32_t inc = wave_inclusive_scan_u32(nch);
+        pref = inc - nch;
+        const uint32_t total = rdl(inc, 63);
+        count_w = total > wave ? (total - wave + NW - 1) / NW : 0u;
+        resolve_and_load(0);
+    };
+
+    // ---- accumulator init (dense-head rows scored by the accumulator's owner, or zero): as in accumulate_tile, with
+    // the sparse prefetch issued right after the first rows have been requested
+    {
+        typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+        constexpr int RG = 4;
+        const uint32_t qv = lane < a.n_pairs ? a.q_dense[(uint64_t)q * a.n_pairs + lane] : 0u;
+        const uint32_t pmask = meta.z;
+        const __amdgpu_buffer_rsrc_t rs_dense =
+            make_rsrc(reinterpret_cast<const char*>(a.dense) + (uint64_t)tile_l * a.n_pairs * (TILE_DOCS * 4u),
+                      a.n_pairs * (uint32_t)(TILE_DOCS * 4));
+        for (int r0 = 0; r0 < rounds; r0 += RG) {
+            uint4 sacc[RG];
+#pragma unroll
+            for (int i = 0; i < RG; ++i) sacc[i] = make_uint4(0, 0, 0, 0);
+            if (pmask) {
+                uint32_t voff[RG];
+#pragma unroll
+                for (int i = 0; i < RG; ++i) voff[i] = ((uint32_t)min(r0 + i, rounds - 1) * NT + tid) * 16u;
+                auto load_rows = [&](uint4 (&x)[RG], uint32_t p) {
+#pragma unroll
+                    for (int i = 0; i < RG; ++i) x[i] = buf_load16(rs_dense, voff[i], p * (uint32_t)(TILE_DOCS * 4));
+                };
+                auto add_rows = [&](const uint4 (&x)[RG], uint32_t qp) {
+                    const us2 qq = __builtin_bit_cast(us2, qp);
+#pragma unroll
+                    for (int i = 0; i < RG; ++i) {
+                        sacc[i].x = __builtin_amdgcn_udot2(__builtin_bit_cast(us2, x[i].x), qq, sacc[i].x, false);
+                        sacc[i].y = __builtin_amdgcn_udot2(__builtin_bit_cast(us2, x[i].y), qq, sacc[i].y, false);
+                        sacc[i].z = __builtin_amdgcn_udot2(__builtin_bit_cast(us2, x[i].z), qq, sacc[i].z, false);
+                        sacc[i].w = __builtin_amdgcn_udot2(__builtin_bit_cast(us2, x[i].w), qq, sacc[i].w, false);
+                    }
+                };
+                uint32_t m = pmask;
+                uint4 xa[RG];
+                for (;;) {  // one pair at a time (light queries hold one or two): the register banks go to the chunks
+                    const uint32_t pa = (uint32_t)__builtin_ctz(m);
+                    m &= m - 1;
+                    load_rows(xa, pa);
+                    if (r0 == 0 && pa == (uint32_t)__builtin_ctz(pmask)) prefetch();
+                    add_rows(xa, rdl(qv, pa));
+                    if (!m) break;
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < RG; ++i)
+                if (r0 + i < rounds) a4[(r0 + i) * NT + tid] = sacc[i];
+        }
+        if (!pmask) prefetch();
+    }
+    if (tid < 64) ss.cnt[tid] = 0;
+    if (tid == 0) {
+        ss.n_cand = 0;
+        ss.tau0 = 1;
+        ss.smax = 0;
+    }
+    stamp(0);
+    __syncthreads();  // every accumulator is initialised
+    add_loaded();
+    for (uint32_t u0 = UL; u0 < count_w; u0 += UL) {  // (rare on this path: more than UL chunks for one wave)
+        resolve_and_load(u0);
+        add_loaded();
+    }
+    stamp(2);
+    __syncthreads();  // accumulation complete
+}
+
 }  // namespace msr

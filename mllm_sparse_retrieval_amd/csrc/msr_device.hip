@@ -30,6 +30,8 @@ static int launch_score(hipStream_t st, uint32_t tile_docs, uint32_t t_begin, ui
         hipLaunchKernelGGL((score_tiles<T, N, UU, W, 512, true>), grid, dim3(N), 0, st, a);        \
     else if (a.dbg)                                                                                \
         hipLaunchKernelGGL((score_tiles<T, N, UU, WR, 1024, true>), grid, dim3(N), 0, st, a);      \
+    else if (a.k <= 512 && a.light && (T == 8192 || T == 4096))                                    \
+        hipLaunchKernelGGL((score_tiles<T, N, UU, W, 512, false, 0, (T == 8192 || T == 4096)>), grid, dim3(N), 0, st, a); \
     else if (a.k <= 512)                                                                           \
         hipLaunchKernelGGL((score_tiles<T, N, UU, W, 512, false>), grid, dim3(N), 0, st, a);       \
     else                                                                                           \
@@ -436,6 +438,7 @@ static int batch_create_impl(msr_index* ix, const int64_t* q_ptr, const int32_t*
     std::vector<uint32_t> dsum(h->n_dense);
     uint64_t n_kept = 0;
     uint64_t sum_df = 0;
+    uint64_t max_sparse = 0;  // most sparse (non dense-head) terms in one query
     for (int i = 0; i < nq; ++i) {
         if (q_ptr[i + 1] < q_ptr[i] || q_ptr[i + 1] > total_in) {
             set_error("q_ptr is not monotone at query %d", i);
@@ -488,6 +491,7 @@ static int batch_create_impl(msr_index* ix, const int64_t* q_ptr, const int32_t*
             set_error("query batch too large");
             return MSR_E_RANGE;
         }
+        max_sparse = std::max<uint64_t>(max_sparse, qterm.size() - qptr[(size_t)i * 4]);
         qptr[(size_t)i * 4 + 1] = (uint32_t)qterm.size();
         qptr[(size_t)i * 4 + 2] = pmask;
         qptr[(size_t)i * 4 + 4] = (uint32_t)qterm.size();  // the next query's first term
@@ -505,6 +509,7 @@ static int batch_create_impl(msr_index* ix, const int64_t* q_ptr, const int32_t*
     b->term_shard = n_shards > 0 ? shard : -1;
     b->term_nshards = n_shards > 0 ? n_shards : 0;
     b->sum_df = sum_df;
+    b->max_sparse_terms = (uint32_t)std::min<uint64_t>(max_sparse, 0xFFFFFFFFull);
     auto fail = [&](int rc) {
         batch_free(b);
         return rc;
@@ -651,6 +656,10 @@ int batch_search_local(msr_batch* b, int k, bool final_arrays) {
     sa.unsorted = 0;
     sa.tpr = 1;
     sa.dump_add = 0;
+    {
+        static const bool no_light = getenv("MSR_NO_LIGHT") != nullptr;  // diagnostic: the general accumulation only
+        sa.light = (!no_light && b->max_sparse_terms <= 64) ? 1u : 0u;
+    }
     {
         const char* dbg = getenv("MSR_DEBUG_FLAGS");
         sa.dbg = dbg ? (uint32_t)strtoul(dbg, nullptr, 0) : 0u;
@@ -1111,6 +1120,7 @@ static void fill_score_args(ScoreArgs& sa, msr_batch* b, int k) {
     sa.dump_add = 0;
     sa.dbg = 0;
     sa.stamps = nullptr;
+    sa.light = 0;
 }
 
 int msr_batch_search_termshard(msr_batch* b, int k) {

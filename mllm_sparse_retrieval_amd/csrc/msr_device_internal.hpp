@@ -130,6 +130,7 @@ struct ScoreArgs {
     uint32_t* dump;
     uint32_t tpr;              // tiles per rank = ceil(n_tiles / G)
     uint32_t dump_add;         // 1: dump[...] += tile (single-GPU emulation of the reduction), 0: store
+    uint32_t light;            // 1: every query of the batch holds <= 64 sparse terms (score_tiles<..., LIGHT>)
     uint32_t dbg;              // MSR_DEBUG_FLAGS (timing ablations only; results are wrong when bits 0-2 are set)
     unsigned long long* stamps;  // [8] summed s_memtime deltas of wave 0 per phase (dbg bit 3), else null
 };
@@ -172,6 +173,7 @@ struct msr_batch {
     int last_k = 0;
     uint64_t nnz = 0;             // kept query entries
     uint64_t sum_df = 0;          // sum over kept entries of df_shard(term)
+    uint32_t max_sparse_terms = 0; // most sparse (non dense-head) terms in one query: <= 64 selects the light kernel
     uint32_t* d_qptr = nullptr;
     uint32_t* d_qterm = nullptr;
     uint32_t* d_qw = nullptr;

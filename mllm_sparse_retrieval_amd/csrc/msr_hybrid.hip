@@ -1307,6 +1307,7 @@ static int hybrid_search_fused(msr_index* ix, msr_dense* dx, const int64_t* q_pt
     sa.dump_add = 0;
     sa.dbg = 0;
     sa.stamps = nullptr;
+    sa.light = 0;
     HybridArgs ha;
     ha.dkeys = d_S;
     ha.ld = ld;

@@ -25,7 +25,8 @@ namespace msr {
 
 // ------------------------------------------------------------------------------------------------ kernel 1
 // <docs per tile, threads, 1-KiB chunk loads per register bank, min waves per SIMD, candidate-key capacity (>= k), diag>
-template <int TILE_DOCS, int NT, int U, int MIN_WAVES, int CAND, bool DBG, int MODE = 0>
+// LIGHT: the batch's queries hold at most 64 sparse terms each -> accumulate_tile_light (msr_accumulate.hpp)
+template <int TILE_DOCS, int NT, int U, int MIN_WAVES, int CAND, bool DBG, int MODE = 0, bool LIGHT = false>
 __global__ __launch_bounds__(NT, MIN_WAVES) void score_tiles(const ScoreArgs a) {
     using L = TileLds<TILE_DOCS, NT, CAND>;
 
@@ -63,7 +64,10 @@ __global__ __launch_bounds__(NT, MIN_WAVES) void score_tiles(const ScoreArgs a) 
 
     // staged search: the query's k-th best key over the tiles of an earlier launch (0: fewer than k hits so far)
     const uint64_t theta = (MODE == 0 && a.theta) ? a.theta[(uint64_t)q * a.k + (a.k - 1)] : 0ull;
-    accumulate_tile<TILE_DOCS, NT, U, DBG>(a, q, tile_l, rounds, lds, ss, stamp, tid);
+    if constexpr (LIGHT)
+        accumulate_tile_light<TILE_DOCS, NT>(a, q, tile_l, rounds, lds, ss, stamp, tid);
+    else
+        accumulate_tile<TILE_DOCS, NT, U, DBG>(a, q, tile_l, rounds, lds, ss, stamp, tid);
     stamp(3);  // waiting for the slowest wave
 
     // =============================================================== exact top-k of this tile
