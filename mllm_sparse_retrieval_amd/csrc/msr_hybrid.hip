@@ -26,9 +26,10 @@ typedef float float16v __attribute__((ext_vector_type(16)));
 constexpr int kGemmRowB = 80;                    // LDS row stride in bytes (64 B of data + 16 B pad)
 constexpr int kGemmTileB = 128 * kGemmRowB;      // one operand stage
 
+// raw != 0: the f32 bit patterns are written as they are (hybrid_tiles takes the row as floats) instead of keys
 __global__ __launch_bounds__(256) void dense_scores(const _Float16* __restrict__ Q, const _Float16* __restrict__ P,
                                                     uint32_t* __restrict__ out, uint32_t M, uint32_t N, uint32_t H,
-                                                    uint64_t ld) {
+                                                    uint64_t ld, uint32_t raw) {
     __shared__ __attribute__((aligned(16))) uint8_t stage[2][2][kGemmTileB];  // [buffer][A|B]
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t r = lane & 31, h = lane >> 5;
@@ -99,7 +100,7 @@ __global__ __launch_bounds__(256) void dense_scores(const _Float16* __restrict__
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const uint32_t q = q_blk + wm + 32 * i + (e & 3) + 8 * (e >> 2) + 4 * h;
-                if (q < M) out[(uint64_t)q * ld + d] = d < N ? f32_to_key(acc[i][j][e]) : 0u;
+                if (q < M) out[(uint64_t)q * ld + d] = d < N ? (raw ? __float_as_uint(acc[i][j][e]) : f32_to_key(acc[i][j][e])) : 0u;
             }
         }
 }
@@ -122,7 +123,7 @@ constexpr int kG2Stage = 2 * 256 * 128;  // bytes per stage: A rows then B rows,
 // (a patch grid dealt out patch by patch was 26 % SLOWER: 20 patches over 8 XCDs is 3 rounds for some, 2 for others).
 __global__ __launch_bounds__(512, 1) void dense_scores_256(const _Float16* __restrict__ Q, const _Float16* __restrict__ P,
                                                            uint32_t* __restrict__ out, uint32_t M, uint32_t N, uint32_t H,
-                                                           uint64_t ld, uint32_t qb_n, uint32_t db_n) {
+                                                           uint64_t ld, uint32_t qb_n, uint32_t db_n, uint32_t raw) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];  // 2 stages
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t r = lane & 31, h = lane >> 5;
@@ -206,7 +207,7 @@ __global__ __launch_bounds__(512, 1) void dense_scores_256(const _Float16* __res
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const uint32_t q = q_blk + wm + 32 * i + (e & 3) + 8 * (e >> 2) + 4 * h;
-                if (q < M) out[(uint64_t)q * ld + d] = d < N ? f32_to_key(acc[i][j][e]) : 0u;
+                if (q < M) out[(uint64_t)q * ld + d] = d < N ? (raw ? __float_as_uint(acc[i][j][e]) : f32_to_key(acc[i][j][e])) : 0u;
             }
         }
 }
@@ -228,7 +229,7 @@ constexpr int kGpStages = 4;
 
 __global__ __launch_bounds__(512, 1) void dense_scores_256p(const _Float16* __restrict__ Q, const _Float16* __restrict__ P,
                                                             uint32_t* __restrict__ out, uint32_t M, uint32_t N, uint32_t H,
-                                                            uint64_t ld, uint32_t qb_n, uint32_t db_n) {
+                                                            uint64_t ld, uint32_t qb_n, uint32_t db_n, uint32_t raw) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];  // 4 sub-step buffers (ONE LDS object)
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = rfl(tid >> 6);
     const uint32_t r = lane & 31, h = lane >> 5;
@@ -355,7 +356,7 @@ __global__ __launch_bounds__(512, 1) void dense_scores_256p(const _Float16* __re
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const uint32_t q = q_blk + wm + 32 * i + (e & 3) + 8 * (e >> 2) + 4 * h;
-                if (q < M) out[(uint64_t)q * ld + d] = d < N ? f32_to_key(acc[i][j][e]) : 0u;
+                if (q < M) out[(uint64_t)q * ld + d] = d < N ? (raw ? __float_as_uint(acc[i][j][e]) : f32_to_key(acc[i][j][e])) : 0u;
             }
         }
 }
@@ -433,7 +434,8 @@ void msr_dense_close(msr_dense* dx) {
 // C = Q * P^T as order-preserving keys into out[q][ld] for doc columns [0, n_cover); rows of Q padded to qn_pad (a
 // multiple of 256), P rows readable up to n_cover. Doc blocks are launched in slices of at most 65535 (grid y limit).
 static int launch_dense_gemm(msr_dense* dx, const _Float16* P, const _Float16* d_Q, uint32_t* d_S, uint32_t qn,
-                             uint32_t qn_pad, uint64_t n_cover, uint64_t ld, hipStream_t st, bool force_256 = false) {
+                             uint32_t qn_pad, uint64_t n_cover, uint64_t ld, hipStream_t st, bool force_256 = false,
+                             bool raw = false) {
     const bool big = dx->h % 64 == 0 && n_cover % 256 == 0 &&
                      (force_256 || (uint64_t)(qn_pad / 256) * (n_cover / 256) >= 256);
     if (big && !dx->lds_attr_set) {  // 128 KiB of dynamic LDS needs the opt-in (per device: kept in the handle)
@@ -452,17 +454,17 @@ static int launch_dense_gemm(msr_dense* dx, const _Float16* P, const _Float16* d
         if (big && !no_patch && !no_pipe) {
             const uint32_t qb_n = qn_pad / 256, db_n = (uint32_t)(nd / 256);
             hipLaunchKernelGGL(dense_scores_256p, dim3((qb_n * db_n + 7) / 8 * 8), dim3(512), kGpStages * kGpStage, st, d_Q,
-                               P + d0 * dx->h, d_S + d0, qn, n_left, dx->h, ld, qb_n, db_n);
+                               P + d0 * dx->h, d_S + d0, qn, n_left, dx->h, ld, qb_n, db_n, raw ? 1u : 0u);
         } else if (big && !no_patch) {
             const uint32_t qb_n = qn_pad / 256, db_n = (uint32_t)(nd / 256);
             hipLaunchKernelGGL(dense_scores_256, dim3((qb_n * db_n + 7) / 8 * 8), dim3(512), 2 * kG2Stage, st, d_Q,
-                               P + d0 * dx->h, d_S + d0, qn, n_left, dx->h, ld, qb_n, db_n);
+                               P + d0 * dx->h, d_S + d0, qn, n_left, dx->h, ld, qb_n, db_n, raw ? 1u : 0u);
         } else if (big)
             hipLaunchKernelGGL(dense_scores_256, dim3(qn_pad / 256, (uint32_t)(nd / 256)), dim3(512), 2 * kG2Stage, st, d_Q,
-                               P + d0 * dx->h, d_S + d0, qn, n_left, dx->h, ld, 0u, 0u);
+                               P + d0 * dx->h, d_S + d0, qn, n_left, dx->h, ld, 0u, 0u, raw ? 1u : 0u);
         else
             hipLaunchKernelGGL(dense_scores, dim3(qn_pad / 128, (uint32_t)(nd / 128)), dim3(256), 0, st, d_Q, P + d0 * dx->h,
-                               d_S + d0, qn, n_left, dx->h, ld);
+                               d_S + d0, qn, n_left, dx->h, ld, raw ? 1u : 0u);
         HIP_TRY(hipGetLastError());
     }
     return MSR_OK;
@@ -733,7 +735,7 @@ __global__ __launch_bounds__(NT) void fuse_tiles(const FuseArgs a) {
 namespace msr {
 
 struct HybridArgs {
-    const uint32_t* dkeys;    // [qn][ld] order-preserving keys of the dense scores of queries q0 .. q0+qn-1, by ORDINAL
+    const uint32_t* dkeys;    // [qn][ld] f32 bit patterns of the dense scores of queries q0 .. q0+qn-1, by ORDINAL
     uint64_t ld;
     const int32_t* self_ord;  // [nq] ordinal to skip (remove_query) or -1; may be null
     uint32_t depth, k;
@@ -745,8 +747,8 @@ struct HybridArgs {
 
 // The rare paths of hybrid_tiles, kept OUT OF LINE: inlined, the general selections' live ranges cost the common path
 // ~100 spilled VGPRs (measured: 316 -> 20 bytes of scratch per lane). `keys` is the thread-interleaved tile of u32 keys
-// (LDS accumulators, or the query's row of dense keys in global memory); dense keys are canonicalised like the fast
-// path's floats (-0 = +0) and docs past the corpus masked out.
+// (LDS accumulators, or the query's row of dense scores — f32 bit patterns — in global memory); dense scores become
+// order-preserving keys, canonicalised like the fast path's floats (-0 = +0), docs past the corpus are masked out.
 template <int TILE_DOCS, int NT>
 __device__ __attribute__((noinline)) uint64_t threshold_general(const uint32_t* keys, int rounds, uint32_t ndocs, uint32_t k,
                                                                 bool dense, uint32_t* hist, uint64_t* cand, HistScratch* hs,
@@ -759,7 +761,7 @@ __device__ __attribute__((noinline)) uint64_t threshold_general(const uint32_t* 
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const uint32_t local = 4u * ((uint32_t)r * NT + tid) + (uint32_t)e;
-                    k4[e] = (r < rounds && local < ndocs) ? f32_to_key(key_to_f32(k4[e]) + 0.0f) : 0u;
+                    k4[e] = (r < rounds && local < ndocs) ? f32_to_key(__uint_as_float(k4[e]) + 0.0f) : 0u;
                 }
                 x = make_uint4(k4[0], k4[1], k4[2], k4[3]);
             }
@@ -830,8 +832,8 @@ __global__ __launch_bounds__(NT, MIN_WAVES) void hybrid_tiles(const ScoreArgs a,
     accumulate_tile<TILE_DOCS, NT, U, false>(a, q, 0u, rounds, lds, ss, [](int) {}, tid);
     stamp(0);
 
-    // ---- the query's row of dense scores (the GEMM wrote order-preserving keys in ORDINAL order) as floats in
-    // registers; docs past the corpus become NaN: min / max skip them, every comparison with them is false
+    // ---- the query's row of dense scores (the GEMM wrote the f32 values in ORDINAL order) in registers; docs past the
+    // corpus become NaN: min / max skip them, every comparison with them is false
     float df[E];
     {
         const uint4* row = reinterpret_cast<const uint4*>(h.dkeys + (uint64_t)blockIdx.x * h.ld);
@@ -843,7 +845,7 @@ __global__ __launch_bounds__(NT, MIN_WAVES) void hybrid_tiles(const ScoreArgs a,
             for (int e = 0; e < 4; ++e) {
                 const uint32_t local = 4u * ((uint32_t)r * NT + tid) + (uint32_t)e;
                 // (+ 0.0f: -0 and +0 are one score; they would be two keys)
-                df[4 * r + e] = (r < rounds && local < ndocs) ? key_to_f32(k4[e]) + 0.0f : __builtin_nanf("");
+                df[4 * r + e] = (r < rounds && local < ndocs) ? __uint_as_float(k4[e]) + 0.0f : __builtin_nanf("");
             }
         }
     }
@@ -1339,7 +1341,7 @@ static int hybrid_search_fused(msr_index* ix, msr_dense* dx, const int64_t* q_pt
             break;
         }
         if (inner_events) (void)hipEventRecord(e[0], d->stream);
-        rc = launch_dense_gemm(dx, dx->d_P_ord, d_Q + (size_t)q0 * dx->h, d_S, qn, qn_pad, n_cover, ld, d->stream, true);
+        rc = launch_dense_gemm(dx, dx->d_P_ord, d_Q + (size_t)q0 * dx->h, d_S, qn, qn_pad, n_cover, ld, d->stream, true, true);
         if (rc != MSR_OK) break;
         if (inner_events) (void)hipEventRecord(e[1], d->stream);
         sa.q0 = q0;
