@@ -868,6 +868,7 @@ __global__ __launch_bounds__(NT, MIN_WAVES) void hybrid_tiles(const ScoreArgs a,
                     dmx = fmaxf(dmx, df[4 * r + e]);
                     dmn = fminf(dmn, df[4 * r + e]);
                 }
+                __builtin_amdgcn_sched_barrier(0);
             }
         smx = wave_max_u32(smx);
         smn1 = wave_max_u32(~smn1);
@@ -888,10 +889,14 @@ __global__ __launch_bounds__(NT, MIN_WAVES) void hybrid_tiles(const ScoreArgs a,
     const float dmax_f = key_to_f32(ds.red[3]), dmin_all = key_to_f32(~ds.red[4]);
     // list sizes: the depth best, or everything that is present
     const uint32_t need_s = min(h.depth, n_s), need_d = min(h.depth, n_d);
-    // ---- pass B: histograms, linear between the smallest and the largest present value of each side
-    const float sc_s = ((float)kHistBins - 0.5f) / (float)(smax_u - smin_u);
-    const float sc_d = ((float)kHistBins - 0.5f) / (dmax_f - dmin_all);
+    // ---- pass B: histograms, linear between the smallest and the largest present value of each side (an absent
+    // sparse score, 0, saturates to bin 0, a doc past the corpus, NaN, converts to bin 0: harmless, the chosen bin's
+    // candidates are filtered by presence). Branch-free: one fused multiply-add,
+    // one conversion and one LDS add per element and side.
+    const float sc_s = ((float)kHistBins - 0.5f) / (float)(smax_u - smin_u), of_s = -(float)smin_u * sc_s;
+    const float sc_d = ((float)kHistBins - 0.5f) / (dmax_f - dmin_all), of_d = -dmin_all * sc_d;
     const bool flat_s = smax_u == smin_u, flat_d = !(dmax_f > dmin_all);  // all equal: no spread to bin on
+    const uint32_t one_s = flat_s ? 0u : 1u, one_d = flat_d ? 0u : 1u;
     auto pack_u16 = [](uint32_t lo, uint32_t hi) -> uint32_t {
         typedef unsigned short us2 __attribute__((ext_vector_type(2)));
         return __builtin_bit_cast(uint32_t, (us2)__builtin_amdgcn_cvt_pk_u16(lo, hi));  // v_cvt_pk_u16_u32 saturates
@@ -904,14 +909,13 @@ __global__ __launch_bounds__(NT, MIN_WAVES) void hybrid_tiles(const ScoreArgs a,
             const uint32_t s4[4] = {x.x, x.y, x.z, x.w};
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                const uint32_t bs = (uint32_t)((float)(s4[e] - smin_u) * sc_s);
-                const uint32_t bd = (uint32_t)((df[4 * r + e] - dmin_all) * sc_d);
-                // branch-free: an absent element adds 0 to whatever bin its garbage maps to (no exec-mask juggling per
-                // element; nearly every doc is present on both sides)
-                atomicAdd(&hist[bs & (kHistBins - 1)], flat_s ? 0u : min(s4[e], 1u));
-                atomicAdd(&hist[kHistBins + (bd & (kHistBins - 1))], (df[4 * r + e] == df[4 * r + e] && !flat_d) ? 1u : 0u);
-                bins[4 * r + e] = pack_u16(bs, bd);  // (saturating: an absent score's bin is garbage)
+                const uint32_t bs = (uint32_t)__builtin_fmaf((float)s4[e], sc_s, of_s);      // <= 1023; absent (0) -> 0
+                const uint32_t bd = (uint32_t)__builtin_fmaf(df[4 * r + e], sc_d, of_d);     // <= 1023; NaN -> 0
+                atomicAdd(&hist[flat_s ? 0u : bs], one_s);
+                atomicAdd(&hist[kHistBins + (flat_d ? 0u : bd)], one_d);
+                bins[4 * r + e] = pack_u16(bs, bd);
             }
+            __builtin_amdgcn_sched_barrier(0);  // one round at a time: hoisting all four rounds' loads costs ~50 spills
         }
     __syncthreads();
     // ---- scan: waves [0, HW) walk the sparse bins from the top, waves [HW, NW) the dense bins; the thread whose bins
@@ -1012,8 +1016,9 @@ __global__ __launch_bounds__(NT, MIN_WAVES) void hybrid_tiles(const ScoreArgs a,
             }
         }
     };
-    if (fast_s) rank_side(0, cnt_s, need_s - ds.above[0]);
-    if (fast_d) rank_side(1, cnt_d, need_d - ds.above[1]);
+    // (the number actually collected: bin 0's count also holds the absent elements that were binned there)
+    if (fast_s) rank_side(0, ds.ncand[0], need_s - ds.above[0]);
+    if (fast_d) rank_side(1, ds.ncand[1], need_d - ds.above[1]);
     __syncthreads();
     uint64_t T_s = ds.T[0], T_d = ds.T[1];
     // ---- rare: a side without spread, or a bin with more than kHistCand elements (mass ties): the general selection
@@ -1034,7 +1039,7 @@ __global__ __launch_bounds__(NT, MIN_WAVES) void hybrid_tiles(const ScoreArgs a,
     const uint32_t self = h.self_ord ? (uint32_t)h.self_ord[q] : 0xFFFFFFFFu;
     // fused scores lie in [min(w,0) sums, max(w,0) sums]
     const float f_lo = fminf(h.w_dense, 0.f) + fminf(h.w_sparse, 0.f), f_hi = fmaxf(h.w_dense, 0.f) + fmaxf(h.w_sparse, 0.f);
-    const float sc_f = ((float)kHistBins - 0.5f) / fmaxf(f_hi - f_lo, 1e-30f);
+    const float sc_f = ((float)kHistBins - 0.5f) / fmaxf(f_hi - f_lo, 1e-30f), of_f = -f_lo * sc_f;
     // w * ((x - min) / den) with the division as a multiplication by 1 / den (<= 1 ulp from the quotient, far inside the
     // 1e-5 the fused scores are held to) — but EXACTLY 1 at x = max, as the quotient is: with alpha = 0.5 the best
     // dense-only doc and the best sparse-only doc tie at exactly 0.5 in the reference, and that tie must stay a tie
@@ -1049,7 +1054,7 @@ __global__ __launch_bounds__(NT, MIN_WAVES) void hybrid_tiles(const ScoreArgs a,
         ss.smax = 0;
     }
     __syncthreads();  // histogram zeroed (the candidate lists that lived there are dead)
-    uint32_t n_mem = 0;
+    uint32_t n_mem = 0;  // this thread's docs in the union of the two lists (without the query's own doc)
 #pragma unroll
     for (int r = 0; r < R; ++r)
         if (r < rounds) {
@@ -1068,17 +1073,13 @@ __global__ __launch_bounds__(NT, MIN_WAVES) void hybrid_tiles(const ScoreArgs a,
                 if (in_s) f += h.w_sparse * ((s4[e] == smax_u && spread_s) ? 1.0f : ((float)s4[e] - smin) * inv_sden);
                 const bool member = (in_d || in_s) && local != self;
                 fk[e] = member ? f32_to_key(f) : 0u;
-                const uint32_t fb = (uint32_t)((f - f_lo) * sc_f);
-                bins[4 * r + e] = member ? fb : 0xFFFFFFFFu;  // (the selection bins are dead: reuse the registers)
                 if (member) {
-                    atomicAdd(&hist[fb], 1u);
+                    atomicAdd(&hist[(uint32_t)__builtin_fmaf(f, sc_f, of_f)], 1u);
                     ++n_mem;
                 }
             }
             a4[r * NT + tid] = make_uint4(fk[0], fk[1], fk[2], fk[3]);
-        } else {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) bins[4 * r + e] = 0xFFFFFFFFu;
+            __builtin_amdgcn_sched_barrier(0);
         }
     n_mem = wave_sum_u32(n_mem);
     if (lane == 0) atomicAdd(&ds.red[5], n_mem);
@@ -1120,38 +1121,44 @@ __global__ __launch_bounds__(NT, MIN_WAVES) void hybrid_tiles(const ScoreArgs a,
             uint32_t cnt = hb[0];
 #pragma unroll
             for (int i = 1; i < BPT; ++i) cnt = b == (uint32_t)i ? hb[i] : cnt;
-            ds.fbin = (uint32_t)(kHistBins - 1) - (BPT * tid + b);
+            const uint32_t fb = (uint32_t)(kHistBins - 1) - (BPT * tid + b);
+            ds.fbin = fb;
             ds.fabove = ab;
-            ds.fcnt = cnt;
+            ds.fcnt = cnt + (fb ? hist[fb - 1] : 0u);  // ... and the bin below it: the collection's margin (see there)
         }
     }
     __syncthreads();
-    const uint32_t n_top = need_f ? ds.fabove + ds.fcnt : 0u;  // members at or above the k-th best's bin
-    if (__builtin_expect(n_top <= 64, 1)) {
-        // the usual case: a handful of members; one wave ranks them and writes the result rows
+    // Members at or above the k-th best's bin, plus the bin below: the fused keys are re-read from the tile (nothing is
+    // kept in registers across the scan) and compared with the KEY of the lower edge of bin fbin - 1 — one whole bin of
+    // margin against the rounding of the bin function, so that every member of bins >= fbin is collected.
+    const uint32_t n_top_est = need_f ? ds.fabove + ds.fcnt : 0u;
+    uint64_t* const top = reinterpret_cast<uint64_t*>(tmax);  // 64 keys
+    bool ranked = false;
+    if (__builtin_expect(n_top_est <= 60, 1)) {
         const uint32_t fbin = ds.fbin;
-        uint64_t* const top = reinterpret_cast<uint64_t*>(tmax);  // 64 keys
-        {   // (the fused keys are re-read from the tile this thread wrote them to: nothing but the bins is kept in
-            // registers across the scan)
-            uint32_t hit = 0;
+        const uint32_t key_edge = fbin > 1 ? f32_to_key(((float)fbin - 1.0f) / sc_f + f_lo) : 1u;
+        if (need_f) {
 #pragma unroll
-            for (int j = 0; j < E; ++j) hit |= (uint32_t)(bins[j] != 0xFFFFFFFFu && bins[j] >= fbin) << j;
-            if (need_f && hit) {
-#pragma unroll
-                for (int r = 0; r < R; ++r)
-                    if (r < rounds && (hit >> (4 * r) & 15u)) {
-                        const uint4 x = a4[r * NT + tid];
-                        const uint32_t k4[4] = {x.x, x.y, x.z, x.w};
+            for (int r = 0; r < R; ++r)
+                if (r < rounds) {
+                    const uint4 x = a4[r * NT + tid];
+                    const uint32_t k4[4] = {x.x, x.y, x.z, x.w};
+                    if (max(max(k4[0], k4[1]), max(k4[2], k4[3])) >= key_edge) {
 #pragma unroll
                         for (int e = 0; e < 4; ++e)
-                            if (hit >> (4 * r + e) & 1u) {
+                            if (k4[e] != 0 && k4[e] >= key_edge) {
                                 const uint32_t local = 4u * ((uint32_t)r * NT + tid) + (uint32_t)e;
-                                top[atomicAdd(&ds.fn, 1u)] = ((uint64_t)k4[e] << 32) | (uint64_t)(0xFFFFFFFFu - local);
+                                const uint32_t pos = atomicAdd(&ds.fn, 1u);
+                                if (pos < 64) top[pos] = ((uint64_t)k4[e] << 32) | (uint64_t)(0xFFFFFFFFu - local);
                             }
                     }
-            }
+                }
         }
         __syncthreads();
+        ranked = ds.fn <= 64;  // (a key on the very edge can add one or two to the estimate; more than 64: general path)
+    }
+    if (__builtin_expect(ranked, 1)) {
+        const uint32_t n_top = ds.fn;
         if (tid < 64) {
             const uint64_t me = tid < n_top ? top[tid] : 0ull;
             const uint32_t lo = (uint32_t)me, hi = (uint32_t)(me >> 32);
