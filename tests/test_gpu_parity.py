@@ -715,6 +715,63 @@ def test_fused_hybrid_tile_vs_oracle_pipeline(m, tmp_path, n, tile, depth, k, al
         dix.close()
 
 
+def test_fused_hybrid_randomised(m, tmp_path):
+    """Fuzz of the fused hybrid kernel against the oracle pipeline: corpus sizes on both sides of the tile / round
+    boundaries, depths from 1 to 1024, k from 1 to 64, alpha incl. 0 and 1, remove_query, short and empty queries
+    (docs with score 0 on the sparse side), small vocabularies (many sparse ties), dense dims 32-160, duplicated passage
+    rows (exact dense ties: ids may differ inside a tie, scores may not)."""
+    from mllm_sparse_retrieval_amd.dense import DenseIndex, hybrid_search, row_to_ordinal
+
+    rng = np.random.default_rng(20251005)
+    for case in range(14):
+        n = int(rng.choice([37, 700, 2047, 2049, 4096, 4097, 6000, 8192]))
+        n_terms = int(rng.choice([6, 60, 2000]))
+        nnz = int(min(n_terms, rng.integers(1, 24)))
+        nq = int(rng.integers(3, 40))
+        qn = int(min(n_terms, rng.integers(0, 12)))
+        depth = int(rng.choice([1, 7, 100, 1000, 1024]))
+        k = int(rng.choice([1, 10, 64]))
+        alpha = float(rng.choice([0.0, 0.3, 0.5, 1.0]))
+        remove = bool(rng.integers(0, 2))
+        h = int(rng.choice([32, 64, 160]))
+        dp = np.arange(0, n * nnz + 1, nnz, dtype=np.uint64)
+        dt = np.concatenate([rng.choice(n_terms, nnz, replace=False) for _ in range(n)]).astype(np.uint32)
+        dw = rng.integers(1, 300, n * nnz).astype(np.uint32)
+        qp = np.arange(0, nq * qn + 1, qn, dtype=np.int64)
+        qt = rng.integers(0, n_terms, nq * qn).astype(np.int32)
+        qw = rng.integers(0, 50, nq * qn).astype(np.int32)
+        ids = [str(int(x)) for x in rng.permutation(n * 3)[:n]]            # ids in no particular order
+        path = m.build_index_from_csr(str(tmp_path / f"z{case}.idx"), dp, dt, dw, n_terms, doc_ids=ids)
+        p = _unit_rows(rng, n, h)
+        if case % 3 == 0:
+            p[1::2] = p[0::2][: len(p[1::2])]                               # every passage row twice: exact dense ties
+        q = _unit_rows(rng, nq, h)
+        qids = [ids[int(i) % n] for i in range(nq)]                          # query ids that ARE doc ids (remove_query)
+        with m.SparseIndex(path, device=0) as ix:
+            assert ix.n_tiles == 1
+            dix = DenseIndex(p)
+            r2o = row_to_ordinal(ix, ids)
+            self_ord = np.array([int(r2o[int(i) % n]) for i in range(nq)], dtype=np.int32) if remove else None
+            ords, fs, cnt, ms = hybrid_search(ix, dix, qp, qt, qw, q, depth, k, alpha, r2o, self_ord)
+            assert ms["fusion"] == 0 and ms["dense_select"] == 0
+            docid_of = ix.docid
+            want, sq = helpers.oracle_hybrid((dp, dt, dw), n_terms, ids, qp, qt, qw, q, p, depth, alpha, np.arange(nq),
+                                             remove, qids)
+            for i in range(nq):
+                ranked = sorted(want[sq[i]].items(), key=lambda kv: (-float(kv[1]), kv[0].encode()))[:k]
+                assert cnt[i] == len(ranked), (case, i, cnt[i], len(ranked))
+                got = [docid_of(int(o)) for o in ords[i, : cnt[i]]]
+                assert len(set(got)) == len(got)
+                for r, (doc, score) in enumerate(ranked):
+                    # scores position by position (a dense tie at the depth boundary may admit the twin row instead:
+                    # the same score then sits on another id)
+                    assert abs(float(fs[i, r]) - float(score)) <= 1e-5, (case, i, r, float(fs[i, r]), float(score))
+                if remove:
+                    assert qids[i] not in got
+            dix.close()
+        os.remove(path)
+
+
 def test_fused_hybrid_mass_ties(m, tmp_path):
     """Every doc holds the same term with the same weight: all sparse scores tie, so the sparse top-`depth` list is the
     `depth` LOWEST ordinals (doc-id string order) — the selection's histogram collapses into one bin and has to split
