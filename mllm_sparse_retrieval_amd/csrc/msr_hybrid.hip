@@ -298,8 +298,9 @@ __global__ __launch_bounds__(512, 1) void dense_scores_256p(const _Float16* __re
     // DMA issue + lgkmcnt), counted vmcnt wait 300, MFMA issue 575, barriers 360 — 2 020 per sub-step for 1 024 cycles of
     // MFMA per SIMD = the 52 % MFMA-busy the counters show, at a clock that sags to ~1.85 GHz under this load (2.55 GHz in
     // the integer kernels). Moving 1, 2 or all 4 DMAs between the MFMAs shortens MEM by < 10 % and lengthens MFMA (908
-    // vs 949 TFLOP/s for all 4); without s_setprio 840. What is left is the fragment-read phase itself and the DMA
-    // latency under load (~4 000 cycles: three sub-steps in flight do not quite cover it).
+    // vs 949 TFLOP/s for all 4); without s_setprio 840; sixteen waves (4 x 4, 64 x 64 each, four per SIMD, one barrier
+    // per sub-step, no ping-pong) 857. What is left is the fragment-read phase itself and the DMA latency under load
+    // (~4 000 cycles: three sub-steps in flight do not quite cover it).
     const uint32_t grp = wave >> 2;
     auto bar = []() { asm volatile("s_barrier" ::: "memory"); };
     auto wait_landed = [&](uint32_t p_next) {  // own pieces of sub-step p_next landed; newer ones (<= 2 sub-steps) stay in flight
