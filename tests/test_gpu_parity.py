@@ -255,6 +255,16 @@ def test_cli_search_end_to_end(m, tmp_path, capsys):
     assert os.path.exists(tmp_path / "runs2" / "fusion.trec")
 
 
+def _free_port():
+    import socket
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
 def test_cli_search_two_ranks_dp_over_queries(m, tmp_path):
     """`search` under a launcher = the reference's DP over queries (src/search.py:115-129,180-182; launcher line
     scripts/search_sparse.sh:14): two ranks (sharing this box's one GPU), each searches its DistributedSampler shard, only
@@ -276,7 +286,7 @@ def test_cli_search_two_ranks_dp_over_queries(m, tmp_path):
         for k2 in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
             env.pop(k2, None)
         cmd = [sys.executable] + (["-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr",
-                                   "127.0.0.1", "--master-port", "29631", "-m", "mllm_sparse_retrieval_amd"]
+                                   "127.0.0.1", "--master-port", str(_free_port()), "-m", "mllm_sparse_retrieval_amd"]
                                   if world > 1 else ["-m", "mllm_sparse_retrieval_amd"])
         p = subprocess.run(cmd + ["search"] + common + ["--save_dir", save] + extra, stdout=subprocess.PIPE,
                            stderr=subprocess.PIPE, env=env, timeout=600)
