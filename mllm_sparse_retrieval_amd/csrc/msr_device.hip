@@ -431,71 +431,115 @@ static int batch_create_impl(msr_index* ix, const int64_t* q_ptr, const int32_t*
         set_error("msr_batch_create: bad CSR arrays");
         return MSR_E_INVAL;
     }
-    qterm.reserve((size_t)total_in);
-    qw.reserve((size_t)total_in);
     const uint32_t n_pairs = d->n_pairs;  // resident pairs (a term shard keeps only the pairs with an owned term)
     std::vector<uint32_t> qdense((size_t)nq * n_pairs, 0u);  // packed 16-bit query weights of the dense-head terms
-    std::vector<uint32_t> dsum(h->n_dense);
+    // Big batches (the 155 070-query Flickr batch spends more time here than on the GPU) are normalised by several
+    // threads, each over a contiguous query range into its own term/weight arrays; the ranges are then laid end to
+    // end, so the result is the serial one.  The error reported is the one of the LOWEST failing query, as in a
+    // serial walk.
+    struct Part {
+        int q0 = 0, q1 = 0;
+        std::vector<uint32_t> term, w;
+        uint64_t n_kept = 0, sum_df = 0, max_sparse = 0;
+        int rc = MSR_OK;
+        char err[192] = {0};
+    };
+    const int n_parts = (nq >= 8192 && total_in >= (1 << 16)) ? std::min(clamp_threads(0), 16) : 1;
+    std::vector<Part> parts((size_t)n_parts);
+    auto normalise = [&](int pi) {
+        Part& pt = parts[(size_t)pi];
+        pt.q0 = (int)((int64_t)nq * pi / n_parts);
+        pt.q1 = (int)((int64_t)nq * (pi + 1) / n_parts);
+        auto bad = [&](int rc, const char* fmt, auto... a) {
+            snprintf(pt.err, sizeof(pt.err), fmt, a...);
+            pt.rc = rc;
+        };
+        std::vector<uint32_t> dsum(h->n_dense);
+        if (pt.q1 > pt.q0 && q_ptr[pt.q0] >= 0 && q_ptr[pt.q1] >= q_ptr[pt.q0] && q_ptr[pt.q1] <= total_in) {
+            pt.term.reserve((size_t)(q_ptr[pt.q1] - q_ptr[pt.q0]));
+            pt.w.reserve((size_t)(q_ptr[pt.q1] - q_ptr[pt.q0]));
+        }
+        for (int i = pt.q0; i < pt.q1; ++i) {
+            if (q_ptr[i] < 0 || q_ptr[i + 1] < q_ptr[i] || q_ptr[i + 1] > total_in)
+                return bad(MSR_E_INVAL, "q_ptr is not monotone at query %d", i);
+            uint64_t bound = 0;
+            const size_t first = pt.term.size();
+            std::fill(dsum.begin(), dsum.end(), 0u);
+            for (int64_t e = q_ptr[i]; e < q_ptr[i + 1]; ++e) {
+                const int32_t t = q_term[e];
+                const int32_t w = q_w[e];
+                if (t < 0 || w <= 0) continue;
+                if ((uint32_t)t >= h->n_terms)
+                    return bad(MSR_E_RANGE, "query %d: term id %d is outside the dictionary (%u terms)", i, t, h->n_terms);
+                if (w > 0xFFFFFF)  // the kernel multiplies with v_mul_u32_u24
+                    return bad(MSR_E_RANGE, "query %d: weight %d of term %d exceeds the supported maximum 16777215", i, w, t);
+                if ((flags & MSR_F_DROP_DF_EQ_N) && ix->host.df[t] == h->n_docs) continue;
+                if (ix->host.df[t] == 0) continue;
+                bound += (uint64_t)w * ix->host.maxw[t];  // the bound covers the WHOLE query, whoever owns the term
+                if ((uint32_t)t < term_lo || (uint32_t)t >= term_hi) continue;
+                pt.sum_df += d->df_shard[t];
+                ++pt.n_kept;
+                const int ds = ix->host.dense_slot[t];
+                if (ds >= 0) {  // dense-head term: repeated entries add up; v_dot2_u32_u16 takes 16-bit weights
+                    if ((uint64_t)dsum[ds] + (uint64_t)w > 0xFFFFull)
+                        return bad(MSR_E_RANGE, "query %d: weight of dense-head term %d exceeds the supported maximum 65535", i, t);
+                    dsum[ds] += (uint32_t)w;
+                } else {
+                    pt.term.push_back((uint32_t)t - d->term_base);  // column of the (possibly term-sharded) segment table
+                    pt.w.push_back((uint32_t)w);
+                }
+            }
+            uint32_t pmask = 0;
+            for (uint32_t s2 = 0; s2 < h->n_dense; ++s2) {
+                if (!dsum[s2]) continue;
+                const int32_t lp = d->pair_local[s2 >> 1];  // >= 0: an owned term's pair is resident by construction
+                qdense[(size_t)i * n_pairs + (uint32_t)lp] |= dsum[s2] << (16 * (s2 & 1));
+                pmask |= 1u << lp;
+            }
+            if (bound > 0xFFFFFFFFull)
+                return bad(MSR_E_OVERFLOW, "query %d: worst-case score %llu exceeds the exact u32 range", i, (unsigned long long)bound);
+            pt.max_sparse = std::max<uint64_t>(pt.max_sparse, pt.term.size() - first);
+            qptr[(size_t)i * 4 + 1] = (uint32_t)(pt.term.size() - first);  // the COUNT for now; made an end offset below
+            qptr[(size_t)i * 4 + 2] = pmask;
+        }
+    };
+    parallel_run(n_parts, normalise);
     uint64_t n_kept = 0;
     uint64_t sum_df = 0;
     uint64_t max_sparse = 0;  // most sparse (non dense-head) terms in one query
-    for (int i = 0; i < nq; ++i) {
-        if (q_ptr[i + 1] < q_ptr[i] || q_ptr[i + 1] > total_in) {
-            set_error("q_ptr is not monotone at query %d", i);
-            return MSR_E_INVAL;
+    uint64_t n_sparse = 0;
+    for (const Part& pt : parts) {  // parts are in query order: the first failing part holds the lowest failing query
+        if (pt.rc != MSR_OK) {
+            set_error("%s", pt.err);
+            return pt.rc;
         }
-        uint64_t bound = 0;
-        std::fill(dsum.begin(), dsum.end(), 0u);
-        for (int64_t e = q_ptr[i]; e < q_ptr[i + 1]; ++e) {
-            const int32_t t = q_term[e];
-            const int32_t w = q_w[e];
-            if (t < 0 || w <= 0) continue;
-            if ((uint32_t)t >= h->n_terms) {
-                set_error("query %d: term id %d is outside the dictionary (%u terms)", i, t, h->n_terms);
-                return MSR_E_RANGE;
-            }
-            if (w > 0xFFFFFF) {  // the kernel multiplies with v_mul_u32_u24
-                set_error("query %d: weight %d of term %d exceeds the supported maximum 16777215", i, w, t);
-                return MSR_E_RANGE;
-            }
-            if ((flags & MSR_F_DROP_DF_EQ_N) && ix->host.df[t] == h->n_docs) continue;
-            if (ix->host.df[t] == 0) continue;
-            bound += (uint64_t)w * ix->host.maxw[t];  // the bound covers the WHOLE query, whoever owns the term
-            if ((uint32_t)t < term_lo || (uint32_t)t >= term_hi) continue;
-            sum_df += d->df_shard[t];
-            ++n_kept;
-            const int ds = ix->host.dense_slot[t];
-            if (ds >= 0) {  // dense-head term: repeated entries add up; v_dot2_u32_u16 takes 16-bit weights
-                if ((uint64_t)dsum[ds] + (uint64_t)w > 0xFFFFull) {
-                    set_error("query %d: weight of dense-head term %d exceeds the supported maximum 65535", i, t);
-                    return MSR_E_RANGE;
-                }
-                dsum[ds] += (uint32_t)w;
-            } else {
-                qterm.push_back((uint32_t)t - d->term_base);  // column of the (possibly term-sharded) segment table
-                qw.push_back((uint32_t)w);
-            }
-        }
-        uint32_t pmask = 0;
-        for (uint32_t s2 = 0; s2 < h->n_dense; ++s2) {
-            if (!dsum[s2]) continue;
-            const int32_t lp = d->pair_local[s2 >> 1];  // >= 0: an owned term's pair is resident by construction
-            qdense[(size_t)i * n_pairs + (uint32_t)lp] |= dsum[s2] << (16 * (s2 & 1));
-            pmask |= 1u << lp;
-        }
-        if (bound > 0xFFFFFFFFull) {
-            set_error("query %d: worst-case score %llu exceeds the exact u32 range", i, (unsigned long long)bound);
-            return MSR_E_OVERFLOW;
-        }
-        if (qterm.size() > 0xFFFFFFF0ull) {
-            set_error("query batch too large");
-            return MSR_E_RANGE;
-        }
-        max_sparse = std::max<uint64_t>(max_sparse, qterm.size() - qptr[(size_t)i * 4]);
-        qptr[(size_t)i * 4 + 1] = (uint32_t)qterm.size();
-        qptr[(size_t)i * 4 + 2] = pmask;
-        qptr[(size_t)i * 4 + 4] = (uint32_t)qterm.size();  // the next query's first term
+        n_kept += pt.n_kept;
+        sum_df += pt.sum_df;
+        max_sparse = std::max(max_sparse, pt.max_sparse);
+        n_sparse += pt.term.size();
     }
+    if (n_sparse > 0xFFFFFFF0ull) {
+        set_error("query batch too large");
+        return MSR_E_RANGE;
+    }
+    qterm.resize((size_t)n_sparse);
+    qw.resize((size_t)n_sparse);
+    std::vector<uint64_t> part_base((size_t)n_parts + 1, 0);
+    for (int pi = 0; pi < n_parts; ++pi) part_base[(size_t)pi + 1] = part_base[(size_t)pi] + parts[(size_t)pi].term.size();
+    parallel_run(n_parts, [&](int pi) {
+        const Part& pt = parts[(size_t)pi];
+        uint32_t at = (uint32_t)part_base[(size_t)pi];
+        if (!pt.term.empty()) {
+            memcpy(qterm.data() + at, pt.term.data(), pt.term.size() * 4);
+            memcpy(qw.data() + at, pt.w.data(), pt.w.size() * 4);
+        }
+        for (int i = pt.q0; i < pt.q1; ++i) {
+            qptr[(size_t)i * 4] = at;
+            at += qptr[(size_t)i * 4 + 1];
+            qptr[(size_t)i * 4 + 1] = at;
+        }
+    });
+    qptr[(size_t)nq * 4] = (uint32_t)n_sparse;  // the sentinel row's first term
 
     msr_batch* b = new (std::nothrow) msr_batch;
     if (!b) {

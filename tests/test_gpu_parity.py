@@ -117,6 +117,48 @@ def test_edge_queries(m, tmp_path):
         assert e[0].shape == (0, 10)
 
 
+def test_big_batch_is_normalised_like_small_batches(m, tmp_path):
+    # a batch of >= 8192 queries is normalised by several host threads (msr_device.hip, batch_create_impl); the result
+    # must be the one of the single-threaded walk that small batches take, ragged/empty/OOV/duplicate queries included
+    n_terms = 3000
+    docs, (qp, qt, qw) = helpers.synth(6000, 48, 20011, 9, n_terms, seed=77)
+    rng = np.random.default_rng(78)
+    qt = qt.copy()
+    qw = qw.copy()
+    qt[rng.random(qt.size) < 0.05] = -1                      # OOV entries
+    qw[rng.random(qw.size) < 0.05] = 0                       # dropped weights
+    dup = rng.random(qt.size) < 0.05
+    qt[1:][dup[1:]] = qt[:-1][dup[1:]]                       # repeated terms (weights add up)
+    path = m.build_index_from_csr(str(tmp_path / "b.idx"), *docs, n_terms, tile_docs=4096)
+    oix, _ = helpers.taat_oracle(docs, n_terms)
+    with m.SparseIndex(path, device=0) as ix:
+        big = ix.search_csr(qp, qt, qw, 10)
+        step = 2500                                          # < 8192: the serial walk
+        for a in range(0, 20011, step):
+            b = min(a + step, 20011)
+            sub = ix.search_csr(qp[a:b + 1] - qp[a], qt[qp[a]:qp[b]], qw[qp[a]:qp[b]], 10)
+            for x, y in zip(big, sub):
+                np.testing.assert_array_equal(x[a:b], y)
+        sel = np.arange(0, 20011, 37)
+        sp = np.concatenate([[0], np.cumsum(qp[sel + 1] - qp[sel])]).astype(np.int64)
+        st = np.concatenate([qt[qp[i]:qp[i + 1]] for i in sel])
+        sw = np.concatenate([qw[qp[i]:qp[i + 1]] for i in sel])
+        want = oix.search(sp, st, sw, 10, threads=8)
+        helpers.assert_same_results(tuple(x[sel] for x in big), want, 10)
+        # two bad queries in different threads' ranges: the LOWEST one is reported, as a serial walk would
+        bt = qt.copy()
+        lo_q, hi_q = 9001, 19000
+        assert qp[lo_q + 1] > qp[lo_q] and qp[hi_q + 1] > qp[hi_q]
+        bt[qp[hi_q]] = n_terms + 5
+        bt[qp[lo_q]] = n_terms + 7
+        with pytest.raises(Exception, match=f"query {lo_q}: term id {n_terms + 7}"):
+            ix.search_csr(qp, bt, qw, 10)
+        bp = qp.copy()
+        bp[15000] = bp[15001] + 1                            # not monotone
+        with pytest.raises(Exception, match="not monotone"):
+            ix.search_csr(bp, qt, qw, 10)
+
+
 def test_df_eq_n_switch(m, tmp_path):
     # term 0 is in every doc: dropped by default (contract T3), kept when the switch is off
     n, V = 500, 20
