@@ -28,8 +28,13 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int kGwStage = 2 * 256 * 64;  // bytes per sub-step buffer
 
-// LAB == 3 builds (scripts/gemm_lab.hip only) stamp the K loop of every block: {shader cycles, 100 MHz ticks}
-__device__ uint64_t g_gemm_lab_stamps[8 * 4096];  // + the block's life in 100 MHz ticks: start, loop start, loop end, stores issued, stores done
+// LAB != 0 instantiations (scripts/gemm_lab.hip only, which defines MSR_GEMM_LAB) stamp the K loop of every block:
+// shader cycles and 100 MHz ticks of the loop, the block's life (start, loop start, loop end, stores issued, stores done)
+#ifdef MSR_GEMM_LAB
+__device__ uint64_t g_gemm_lab_stamps[8 * 4096];
+#else
+extern __device__ uint64_t g_gemm_lab_stamps[];  // never referenced by the LAB == 0 instantiations the library builds
+#endif
 
 // XCD-aware patch-major block order shared by the 256 x 256 kernels: workgroup L runs on XCD L % 8 as that XCD's
 // (L / 8)-th block; every XCD walks a contiguous eighth of the order (patches of 8 query blocks x 4 doc blocks)
@@ -353,6 +358,368 @@ __global__ __launch_bounds__(256, 1) void dense_scores_256r(const _Float16* __re
     }
     store_block_via_lds<2 * kGwStage>(acc, smem, out, M, N, ld, q_blk, d_blk, wave, lane, raw);
     if constexpr (LAB == 3 || LAB == 4) {
+        const uint64_t issued = __builtin_amdgcn_s_memrealtime();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (tid == 0 && blockIdx.x < 4096)
+            g_gemm_lab_stamps[8 * blockIdx.x + 2] = life0, g_gemm_lab_stamps[8 * blockIdx.x + 3] = __builtin_amdgcn_s_memrealtime(),
+            g_gemm_lab_stamps[8 * blockIdx.x + 6] = issued;
+    }
+}
+
+// dense_scores_256r16: dense_scores_256r on v_mfma_f32_16x16x32_f16. Same FLOPs per cycle as the 32 x 32 x 16 shape, but
+// the chip holds a higher clock under it (MI355X_MICROARCH.md, DVFS give-back (7): 1.12-1.15 x the FLOP/s on random data;
+// the vendor library's kernels for this shape are MI16x16 too). Wave tile 128 x 128 = 8 x 8 tiles, one K step of 32 per
+// sub-step: 64 MFMAs of 16 cycles, 8 + 8 fragment reads. Fragment map: lane (c = l & 15, g = l >> 4) holds k = 8g .. 8g+7
+// of row c of A / of column c of B; C/D: column l & 15, rows 4 (l >> 4) + reg. LDS rows of 64 B with slot swizzle
+// slot ^= (row >> 2) & 2 (conflict-free for the four 16-lane groups of ds_read_b128 under THIS lane -> (row, slot) map;
+// found by enumeration).
+typedef float float4v __attribute__((ext_vector_type(4)));
+
+template <int LAB = 0>
+__global__ __launch_bounds__(256, 1) void dense_scores_256r16(const _Float16* __restrict__ Q, const _Float16* __restrict__ P,
+                                                              uint32_t* __restrict__ out, uint32_t M, uint32_t N, uint32_t H,
+                                                              uint64_t ld, uint32_t qb_n, uint32_t db_n, uint32_t raw) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];  // 2 buffers of kGwStage
+    uint64_t life0 = 0;
+    if constexpr (LAB == 3) life0 = __builtin_amdgcn_s_memrealtime();
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = rfl(tid >> 6);
+    const uint32_t c = lane & 15, g = lane >> 4;
+    uint32_t qb, db;
+    if (!patch_major_block(blockIdx.x, qb_n, db_n, qb, db)) return;
+    const uint32_t q_blk = qb * 256, d_blk = db * 256;
+    if (d_blk >= N) {  // padding docs: keys 0
+        for (uint32_t i = tid; i < 256 * 64; i += 256) {
+            const uint32_t q = q_blk + i / 64;
+            if (q < M) reinterpret_cast<uint4*>(out + (uint64_t)q * ld + d_blk)[i % 64] = make_uint4(0, 0, 0, 0);
+        }
+        return;
+    }
+    const uint32_t wr = wave >> 1, wm = wr * 128, wn = (wave & 1) * 128;
+    float4v acc[8][8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[i][j][e] = 0.f;
+    const char* const qbase = reinterpret_cast<const char*>(Q + (uint64_t)q_blk * H);
+    const char* const pbase = reinterpret_cast<const char*>(P + (uint64_t)d_blk * H);
+    uint32_t goff[4], loff[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const uint32_t row = (tid >> 2) + 64 * i, seg = tid & 3;
+        goff[i] = row * H * 2 + seg * 16;
+        loff[i] = row * 64 + (seg ^ ((row >> 2) & 2)) * 16;
+    }
+    const uint32_t KP = H / 32;
+    auto gload = [&](u32x4 (&ra)[4], u32x4 (&rb)[4], uint32_t p) {
+        const uint64_t k0 = (uint64_t)min(p, KP - 1) * 64;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            ra[i] = *reinterpret_cast<const u32x4*>(qbase + k0 + goff[i]);
+            rb[i] = *reinterpret_cast<const u32x4*>(pbase + k0 + goff[i]);
+        }
+    };
+    auto lstore = [&](const u32x4 (&ra)[4], const u32x4 (&rb)[4], uint32_t stage) {
+        uint8_t* const st = smem + stage * kGwStage;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            *reinterpret_cast<u32x4*>(st + loff[i]) = ra[i];
+            *reinterpret_cast<u32x4*>(st + 256 * 64 + loff[i]) = rb[i];
+        }
+    };
+    // rows wm + 16 i + c: (row >> 2) & 2 == (c >> 2) & 2
+    const uint32_t fslot = (g ^ ((c >> 2) & 2)) * 16;
+    const uint32_t fa = (wm + c) * 64 + fslot, fb = 256 * 64 + (wn + c) * 64 + fslot;
+    auto read_frags = [&](half8 (&a)[8], half8 (&b)[8], uint32_t stage) {
+        const uint8_t* const st = smem + stage * kGwStage;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            a[i] = *reinterpret_cast<const half8*>(st + fa + i * 16 * 64);
+            b[i] = *reinterpret_cast<const half8*>(st + fb + i * 16 * 64);
+        }
+    };
+    auto bar = []() { asm volatile("s_barrier" ::: "memory"); };
+    auto step = [&](uint32_t p, uint32_t cur, half8 (&ca)[8], half8 (&cb)[8], half8 (&na)[8], half8 (&nb)[8], u32x4 (&ra)[4],
+                    u32x4 (&rb)[4]) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        bar();
+        // The MFMAs are inline asm with the accumulator tied in place in AGPRs: left to the register allocator, 64
+        // four-register accumulator tuples end in a storm of accvgpr copies and scratch spills. Inline asm is invisible
+        // to the sched_group_barrier classes, so the issue order is pinned by hand with sched_barrier(0): 32 MFMAs with
+        // one fragment read of the next sub-step after every second one, then 32 with a ds_write + a global load after
+        // every fourth.
+        const uint8_t* const stn = smem + (cur ^ 1) * kGwStage;
+        uint8_t* const stw = smem + cur * kGwStage;
+        const uint64_t k0 = (uint64_t)min(p + 4, KP - 1) * 64;
+#pragma unroll
+        for (int m = 0; m < 64; ++m) {
+            const int i = m >> 3, j = m & 7;
+            asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(acc[i][j]) : "v"(ca[i]), "v"(cb[j]));
+            if (m < 32 && (m & 1)) {
+                const int q = m >> 1;  // 0..15: a0 b0 a1 b1 ... in the order the next sub-step consumes them (b first rows)
+                if (q < 8) nb[q] = *reinterpret_cast<const half8*>(stn + fb + q * 16 * 64);
+                else na[q - 8] = *reinterpret_cast<const half8*>(stn + fa + (q - 8) * 16 * 64);
+            }
+            if (m >= 32 && (m & 3) == 3) {
+                const int q = (m - 32) >> 2;  // 0..7
+                if (q < 4) {
+                    *reinterpret_cast<u32x4*>(stw + loff[q]) = ra[q];
+                    ra[q] = *reinterpret_cast<const u32x4*>(qbase + k0 + goff[q]);
+                } else {
+                    *reinterpret_cast<u32x4*>(stw + 256 * 64 + loff[q - 4]) = rb[q - 4];
+                    rb[q - 4] = *reinterpret_cast<const u32x4*>(pbase + k0 + goff[q - 4]);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    half8 a0[8], b0[8], a1[8], b1[8];
+    u32x4 ra0[4], rb0[4], ra1[4], rb1[4];
+    gload(ra0, rb0, 0);
+    gload(ra1, rb1, 1);
+    lstore(ra0, rb0, 0);
+    lstore(ra1, rb1, 1);
+    gload(ra0, rb0, 2);
+    gload(ra1, rb1, 3);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    bar();
+    read_frags(a0, b0, 0);
+    uint64_t t0 = 0, r0 = 0;
+    if constexpr (LAB == 3) t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+    for (uint32_t p = 0; p < KP; p += 2) {  // KP is even (H % 64 == 0)
+        step(p, 0, a0, b0, a1, b1, ra0, rb0);
+        step(p + 1, 1, a1, b1, a0, b0, ra1, rb1);
+    }
+    if constexpr (LAB == 3) {
+        const uint64_t t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+        if (tid == 0 && blockIdx.x < 4096)
+            g_gemm_lab_stamps[8 * blockIdx.x] = t1 - t0, g_gemm_lab_stamps[8 * blockIdx.x + 1] = r1 - r0, g_gemm_lab_stamps[8 * blockIdx.x + 4] = r0,
+            g_gemm_lab_stamps[8 * blockIdx.x + 5] = r1;
+    }
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");  // the last MFMAs' results before any accvgpr read (hazard not seen through asm)
+    // ---- epilogue through LDS (see store_block_via_lds): pass t carries the tile rows i = 2t, 2t + 1 of every wave:
+    // 64 query rows (2 wave rows x 32) x 256 docs
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    bar();
+    float* const stg = reinterpret_cast<float*>(smem);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        if (t) bar();  // the previous pass has been read out
+#pragma unroll
+        for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) stg[(wr * 32 + 16 * ii + 4 * g + e) * 256 + wn + 16 * j + c] = acc[2 * t + ii][j][e];
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        bar();
+        u32x4 v[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) v[k] = *reinterpret_cast<const u32x4*>(stg + (wave * 16 + k) * 256 + lane * 4);
+        const uint32_t d = d_blk + lane * 4;
+        const uint32_t keep0 = d + 0 < N ? ~0u : 0u, keep1 = d + 1 < N ? ~0u : 0u, keep2 = d + 2 < N ? ~0u : 0u,
+                       keep3 = d + 3 < N ? ~0u : 0u;
+        const uint32_t as_key = raw ? 0u : ~0u;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const uint32_t row = wave * 16 + k;
+            const uint32_t q = q_blk + (row >> 5) * 128 + 32 * t + (row & 31);
+            u32x4 o = v[k];
+#pragma unroll
+            for (int x = 0; x < 4; ++x) o[x] ^= (((uint32_t)((int32_t)o[x] >> 31)) | 0x80000000u) & as_key;
+            o[0] &= keep0, o[1] &= keep1, o[2] &= keep2, o[3] &= keep3;
+            if (q < M) *reinterpret_cast<u32x4*>(out + (uint64_t)q * ld + d) = o;
+        }
+    }
+    if constexpr (LAB == 3) {
+        const uint64_t issued = __builtin_amdgcn_s_memrealtime();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (tid == 0 && blockIdx.x < 4096)
+            g_gemm_lab_stamps[8 * blockIdx.x + 2] = life0, g_gemm_lab_stamps[8 * blockIdx.x + 3] = __builtin_amdgcn_s_memrealtime(),
+            g_gemm_lab_stamps[8 * blockIdx.x + 6] = issued;
+    }
+}
+
+// dense_scores_256k: the four-wave 128 x 128 tiling on v_mfma_f32_16x16x32_f16 with K steps of 64 — every global load
+// fetches FULL 128-byte lines (8 lanes per row; the 32-deep kernels above fetch every line twice, 64 B at a time: twice
+// the TA / L2 requests), ONE register set of 16 x 16 B per lane stages a step, and two 64-KiB LDS buffers hold a step
+// each (rows of 128 B, slot swizzle slot ^= (row >> 1) & 7: conflict-free for the 16 x 16 x 32 fragment reads, by
+// enumeration, and for the 8-lane row writes). One barrier per 64-deep step:
+//   half 0 of step S : 64 MFMAs on fragments(S, k-half 0) | read fragments(S, k-half 1) from buffer S & 1
+//   mid              : lgkmcnt(0) + barrier   — every wave is done with buffer S & 1; step S + 1 is complete in the other
+//   half 1 of step S : 64 MFMAs on fragments(S, k-half 1) | read fragments(S + 1, k-half 0) from the other buffer,
+//                      write the staged step S + 2 into buffer S & 1, then load step S + 3 into the staging registers
+// (the staged data was requested one and a half steps earlier). MFMAs are inline asm with the accumulator tied in place
+// (see dense_scores_256r16); the issue order is pinned with sched_barrier(0).
+constexpr int kGkStage = 2 * 256 * 128;  // bytes per 64-deep step buffer: A rows then B rows
+
+template <int LAB = 0>
+__global__ __launch_bounds__(256, 1) void dense_scores_256k(const _Float16* __restrict__ Q, const _Float16* __restrict__ P,
+                                                            uint32_t* __restrict__ out, uint32_t M, uint32_t N, uint32_t H,
+                                                            uint64_t ld, uint32_t qb_n, uint32_t db_n, uint32_t raw) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];  // 2 buffers of kGkStage
+    uint64_t life0 = 0;
+    if constexpr (LAB == 3) life0 = __builtin_amdgcn_s_memrealtime();
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = rfl(tid >> 6);
+    const uint32_t c = lane & 15, g = lane >> 4;
+    uint32_t qb, db;
+    if (!patch_major_block(blockIdx.x, qb_n, db_n, qb, db)) return;
+    const uint32_t q_blk = qb * 256, d_blk = db * 256;
+    if (d_blk >= N) {  // padding docs: keys 0
+        for (uint32_t i = tid; i < 256 * 64; i += 256) {
+            const uint32_t q = q_blk + i / 64;
+            if (q < M) reinterpret_cast<uint4*>(out + (uint64_t)q * ld + d_blk)[i % 64] = make_uint4(0, 0, 0, 0);
+        }
+        return;
+    }
+    const uint32_t wr = wave >> 1, wm = wr * 128, wn = (wave & 1) * 128;
+    float4v acc[8][8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[i][j][e] = 0.f;
+    // staging plan: chunk tid + 256 i (i = 0..7) of an operand's step = 16 B: row (tid >> 3) + 32 i, segment tid & 7
+    // (eight lanes fetch one 128-byte line); LDS slot = segment ^ ((row >> 1) & 7), the same for every i
+    const char* const qbase = reinterpret_cast<const char*>(Q + (uint64_t)q_blk * H);
+    const char* const pbase = reinterpret_cast<const char*>(P + (uint64_t)d_blk * H);
+    const uint32_t srow = tid >> 3, sseg = tid & 7;
+    const uint32_t goff = srow * H * 2 + sseg * 16;
+    const uint32_t loff = srow * 128 + (sseg ^ ((srow >> 1) & 7)) * 16;
+    const uint64_t gstep = (uint64_t)32 * H * 2;  // 32 rows further
+    const uint32_t KS = H / 64;
+    u32x4 ra[8], rb[8];
+    auto gload_all = [&](uint32_t S) {
+        const uint64_t k0 = (uint64_t)min(S, KS - 1) * 128;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) ra[i] = *reinterpret_cast<const u32x4*>(qbase + k0 + i * gstep + goff);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) rb[i] = *reinterpret_cast<const u32x4*>(pbase + k0 + i * gstep + goff);  // (the loop's order)
+    };
+    auto lstore_all = [&](uint32_t stage) {
+        uint8_t* const st = smem + stage * kGkStage;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            *reinterpret_cast<u32x4*>(st + loff + i * 32 * 128) = ra[i];
+            *reinterpret_cast<u32x4*>(st + 256 * 128 + loff + i * 32 * 128) = rb[i];
+        }
+    };
+    // fragment addresses: row (w? + 16 i + c) -> swizzle (c >> 1) & 7; k-half h reads slot (4 h + g) ^ swizzle
+    const uint32_t fs0 = (g ^ ((c >> 1) & 7)) * 16, fs1 = fs0 ^ 64;
+    const uint32_t fa = (wm + c) * 128, fb = 256 * 128 + (wn + c) * 128;
+    auto bar = []() { asm volatile("s_barrier" ::: "memory"); };
+    half8 xa[8], xb[8], ya[8], yb[8];
+    // ---- prologue: steps 0 and 1 into the LDS buffers, step 2 into the staging registers
+    gload_all(0);
+    lstore_all(0);
+    gload_all(1);
+    lstore_all(1);
+    gload_all(2);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    bar();
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        xa[i] = *reinterpret_cast<const half8*>(smem + fa + i * 16 * 128 + fs0);
+        xb[i] = *reinterpret_cast<const half8*>(smem + fb + i * 16 * 128 + fs0);
+    }
+    uint64_t t0 = 0, r0 = 0;
+    if constexpr (LAB == 3) t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+    uint64_t lap0 = 0, lap1 = 0, lap2 = 0;
+    for (uint32_t S = 0; S < KS; ++S) {
+        uint64_t s0 = 0, s1 = 0, s2 = 0;
+        if constexpr (LAB >= 5) s0 = __builtin_amdgcn_s_memtime();
+        const uint8_t* const cur = smem + (S & 1) * kGkStage;
+        const uint8_t* const oth = smem + ((S & 1) ^ 1) * kGkStage;
+        uint8_t* const curw = smem + (S & 1) * kGkStage;
+        // ---- half 0
+#pragma unroll
+        for (int m = 0; m < 64; ++m) {
+            const int i = m >> 3, j = m & 7;
+            asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(acc[i][j]) : "v"(xa[i]), "v"(xb[j]));
+            if (m < 32 && (m & 1)) {
+                const int q = m >> 1;
+                if (q < 8) yb[q] = *reinterpret_cast<const half8*>(cur + fb + q * 16 * 128 + fs1);
+                else ya[q - 8] = *reinterpret_cast<const half8*>(cur + fa + (q - 8) * 16 * 128 + fs1);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if constexpr (LAB >= 5) s1 = __builtin_amdgcn_s_memtime();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        bar();
+        if constexpr (LAB >= 5) s2 = __builtin_amdgcn_s_memtime();
+        // ---- half 1
+        const uint64_t k0 = (uint64_t)min(S + 3, KS - 1) * 128;
+#pragma unroll
+        for (int m = 0; m < 64; ++m) {
+            const int i = m >> 3, j = m & 7;
+            asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(acc[i][j]) : "v"(ya[i]), "v"(yb[j]));
+            if (m < 32 && (m & 1)) {
+                const int q = m >> 1;  // a fragment read of the next step per second MFMA
+                if (q < 8) xb[q] = *reinterpret_cast<const half8*>(oth + fb + q * 16 * 128 + fs0);
+                else xa[q - 8] = *reinterpret_cast<const half8*>(oth + fa + (q - 8) * 16 * 128 + fs0);
+            }
+            if ((m & 3) == 2) {
+                // a staged store per fourth MFMA (the LDS store path moves ~79 B/clk for the whole CU: packed more
+                // densely the stores stall their waves), each followed by the load that refills its registers
+                const int q = m >> 2;
+                if (q < 8) {
+                    if constexpr (LAB != 7) *reinterpret_cast<u32x4*>(curw + loff + q * 32 * 128) = ra[q];
+                    if constexpr (LAB != 6) ra[q] = *reinterpret_cast<const u32x4*>(qbase + k0 + q * gstep + goff);
+                } else {
+                    if constexpr (LAB != 7) *reinterpret_cast<u32x4*>(curw + 256 * 128 + loff + (q - 8) * 32 * 128) = rb[q - 8];
+                    if constexpr (LAB != 6) rb[q - 8] = *reinterpret_cast<const u32x4*>(pbase + k0 + (q - 8) * gstep + goff);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if constexpr (LAB >= 5) lap0 += s1 - s0, lap1 += s2 - s1, lap2 += __builtin_amdgcn_s_memtime() - s2;
+    }
+    if constexpr (LAB >= 5)
+        if (tid == 0 && blockIdx.x < 4096)
+            g_gemm_lab_stamps[8 * blockIdx.x] = lap0, g_gemm_lab_stamps[8 * blockIdx.x + 1] = lap1, g_gemm_lab_stamps[8 * blockIdx.x + 2] = lap2;
+    if constexpr (LAB == 3) {
+        const uint64_t t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+        if (tid == 0 && blockIdx.x < 4096)
+            g_gemm_lab_stamps[8 * blockIdx.x] = (t1 - t0) / 2, g_gemm_lab_stamps[8 * blockIdx.x + 1] = (r1 - r0) / 2,
+            g_gemm_lab_stamps[8 * blockIdx.x + 4] = r0, g_gemm_lab_stamps[8 * blockIdx.x + 5] = r1;
+    }
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");  // the last MFMAs' results before any accvgpr read (hazard not seen through asm)
+    // ---- epilogue through LDS (see store_block_via_lds): pass t carries the tile rows i = 2t, 2t + 1 of every wave:
+    // 64 query rows (2 wave rows x 32) x 256 docs = 64 KiB, alternating between the two step buffers
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    bar();
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        float* const stg = reinterpret_cast<float*>(smem + (t & 1) * kGkStage);
+#pragma unroll
+        for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) stg[(wr * 32 + 16 * ii + 4 * g + e) * 256 + wn + 16 * j + c] = acc[2 * t + ii][j][e];
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        bar();
+        u32x4 v[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) v[k] = *reinterpret_cast<const u32x4*>(stg + (wave * 16 + k) * 256 + lane * 4);
+        const uint32_t d = d_blk + lane * 4;
+        const uint32_t keep0 = d + 0 < N ? ~0u : 0u, keep1 = d + 1 < N ? ~0u : 0u, keep2 = d + 2 < N ? ~0u : 0u,
+                       keep3 = d + 3 < N ? ~0u : 0u;
+        const uint32_t as_key = raw ? 0u : ~0u;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const uint32_t row = wave * 16 + k;
+            const uint32_t q = q_blk + (row >> 5) * 128 + 32 * t + (row & 31);
+            u32x4 o = v[k];
+#pragma unroll
+            for (int x = 0; x < 4; ++x) o[x] ^= (((uint32_t)((int32_t)o[x] >> 31)) | 0x80000000u) & as_key;
+            o[0] &= keep0, o[1] &= keep1, o[2] &= keep2, o[3] &= keep3;
+            if (q < M) *reinterpret_cast<u32x4*>(out + (uint64_t)q * ld + d) = o;
+        }
+    }
+    if constexpr (LAB == 3) {
         const uint64_t issued = __builtin_amdgcn_s_memrealtime();
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (tid == 0 && blockIdx.x < 4096)

@@ -2,6 +2,7 @@
 // the GPU (fuse_tiles), the log1p-relu top-k sparsifier (sparsify_keys), and their C-ABI entry points. Selection and
 // list merging reuse the search path's kernels (launch_select / launch_merge, msr_device.hip).
 #include "msr_accumulate.hpp"
+#include "msr_gemm_w4.hpp"
 
 using namespace msr;
 
@@ -12,9 +13,6 @@ using namespace msr;
 // (v_mfma_f32_32x32x16_f16, f32 accumulate), written as order-preserving u32 keys into the accumulator layout of
 // select_tiles, so that top-`depth` selection and the tile merge are the SAME kernels as on the sparse path.
 namespace msr {
-
-typedef _Float16 half8 __attribute__((ext_vector_type(8)));
-typedef float float16v __attribute__((ext_vector_type(16)));
 
 
 // One workgroup = 4 waves = a 128 (queries) x 128 (docs) block, each wave 64 x 64 = 2 x 2 MFMA tiles of 32 x 32.
@@ -444,6 +442,8 @@ static int launch_dense_gemm(msr_dense* dx, const _Float16* P, const _Float16* d
                                     hipFuncAttributeMaxDynamicSharedMemorySize, 2 * kG2Stage));
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(dense_scores_256p),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, kGpStages * kGpStage));
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(dense_scores_256k<0>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 2 * kGkStage));
         dx->lds_attr_set = true;
     }
     const uint64_t blk = big ? 256 : 128;
@@ -452,7 +452,12 @@ static int launch_dense_gemm(msr_dense* dx, const _Float16* P, const _Float16* d
         const uint32_t n_left = dx->n > d0 ? (uint32_t)std::min<uint64_t>(dx->n - d0, 0xFFFFFFFFull) : 0u;
         static const bool no_patch = getenv("MSR_GEMM_NO_PATCH") != nullptr;  // diagnostic: the plain 2-D grid
         static const bool no_pipe = getenv("MSR_GEMM_NO_PIPE") != nullptr;    // diagnostic: the 2-buffer kernel
-        if (big && !no_patch && !no_pipe) {
+        static const bool pingpong = getenv("MSR_GEMM_PINGPONG") != nullptr;  // diagnostic: the 8-wave ping-pong kernel
+        if (big && !no_patch && !no_pipe && !pingpong) {
+            const uint32_t qb_n = qn_pad / 256, db_n = (uint32_t)(nd / 256);
+            hipLaunchKernelGGL(dense_scores_256k<0>, dim3((qb_n * db_n + 7) / 8 * 8), dim3(256), 2 * kGkStage, st, d_Q,
+                               P + d0 * dx->h, d_S + d0, qn, n_left, dx->h, ld, qb_n, db_n, raw ? 1u : 0u);
+        } else if (big && !no_patch && !no_pipe) {
             const uint32_t qb_n = qn_pad / 256, db_n = (uint32_t)(nd / 256);
             hipLaunchKernelGGL(dense_scores_256p, dim3((qb_n * db_n + 7) / 8 * 8), dim3(512), kGpStages * kGpStage, st, d_Q,
                                P + d0 * dx->h, d_S + d0, qn, n_left, dx->h, ld, qb_n, db_n, raw ? 1u : 0u);

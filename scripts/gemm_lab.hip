@@ -1,6 +1,7 @@
 // Lab harness for the config-5 dense GEMM kernels: runs dense_scores_256w<NBUF, LAB> on random fp16 data at the bench shape,
 // checks a sample of the scores against a plain per-element dot product computed on the device in f32, and times it
 // with HIP events. Diagnostic only (scripts/gpu_gemm_lab.sh builds and runs it on the GPU box).
+#define MSR_GEMM_LAB 1
 #include "../mllm_sparse_retrieval_amd/csrc/msr_gemm_w4.hpp"
 
 #include <algorithm>
@@ -84,12 +85,26 @@ int main(int argc, char** argv) {
     CK(hipStreamCreate(&st));
     float ms = 0;
     const int lab = argc > 6 ? atoi(argv[6]) : 0;
-    int rc = nbuf == 2 ? run_kernel(lab == 1 ? dense_scores_256r<1> : lab == 3 ? dense_scores_256r<3> : lab == 4 ? dense_scores_256r<4> : dense_scores_256r<0>, 2 * kGwStage, dq, dp, dout, M, N, H, ld, reps, st, &ms)
+    int rc = nbuf == 64 ? run_kernel(lab == 3 ? dense_scores_256k<3> : lab == 5 ? dense_scores_256k<5> : lab == 6 ? dense_scores_256k<6> : lab == 7 ? dense_scores_256k<7> : dense_scores_256k<0>, 2 * kGkStage, dq, dp, dout, M, N, H, ld, reps, st, &ms)
+             : nbuf == 16 ? run_kernel(lab == 3 ? dense_scores_256r16<3> : dense_scores_256r16<0>, 2 * kGwStage, dq, dp, dout, M, N, H, ld, reps, st, &ms)
+             : nbuf == 2 ? run_kernel(lab == 1 ? dense_scores_256r<1> : lab == 3 ? dense_scores_256r<3> : lab == 4 ? dense_scores_256r<4> : dense_scores_256r<0>, 2 * kGwStage, dq, dp, dout, M, N, H, ld, reps, st, &ms)
              : lab == 3 ? run<4, 3>(dq, dp, dout, M, N, H, ld, reps, st, &ms)
              : lab == 1 ? run<4, 1>(dq, dp, dout, M, N, H, ld, reps, st, &ms) : nbuf == 5 ? run<5>(dq, dp, dout, M, N, H, ld, reps, st, &ms)
                        : (nbuf == 3 ? run<3>(dq, dp, dout, M, N, H, ld, reps, st, &ms) : run<4>(dq, dp, dout, M, N, H, ld, reps, st, &ms));
     if (rc) return rc;
     printf("dense_scores_256w<%d, lab %d> %u x %u x %u: %.4f ms  %.1f TFLOP/s\n", nbuf, lab, M, N, H, ms, 2.0 * M * N * H / (ms * 1e-3) / 1e12);
+    if (lab >= 5) {  // per-phase laps of the 64-deep kernel: cycles per step in half 0, wait + barrier, half 1
+        std::vector<uint64_t> stamps(8 * 4096);
+        CK(hipMemcpyFromSymbol(stamps.data(), HIP_SYMBOL(g_gemm_lab_stamps), stamps.size() * 8));
+        const uint32_t nb = std::min<uint32_t>(4096, ((M + 255) / 256) * ((N + 255) / 256));
+        std::vector<double> l0, l1, l2;
+        for (uint32_t b = 0; b < nb; ++b)
+            if (stamps[8 * b]) l0.push_back(stamps[8 * b] / (H / 64.0)), l1.push_back(stamps[8 * b + 1] / (H / 64.0)), l2.push_back(stamps[8 * b + 2] / (H / 64.0));
+        std::sort(l0.begin(), l0.end()), std::sort(l1.begin(), l1.end()), std::sort(l2.begin(), l2.end());
+        if (!l0.empty())
+            printf("laps per 64-deep step (median cycles): half 0 %.0f, wait + barrier %.0f, half 1 %.0f (1024 per half = MFMA-bound)\n", l0[l0.size() / 2],
+                   l1[l1.size() / 2], l2[l2.size() / 2]);
+    }
     if (lab == 3 || lab == 4) {  // stamps of the last launch: K-loop cycles per 32-deep sub-step, in-kernel clock, block lives
         std::vector<uint64_t> stamps(8 * 4096);
         CK(hipMemcpyFromSymbol(stamps.data(), HIP_SYMBOL(g_gemm_lab_stamps), stamps.size() * 8));
