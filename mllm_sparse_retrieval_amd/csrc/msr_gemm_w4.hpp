@@ -18,6 +18,8 @@
 // the vmcnt bookkeeping is one constant and the loop body is one basic block.
 #pragma once
 
+#include <type_traits>
+
 #include "msr_select.hpp"
 
 namespace msr {
@@ -25,6 +27,16 @@ namespace msr {
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef float float16v __attribute__((ext_vector_type(16)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+// compile-time loop: f(std::integral_constant<int, I>) for I = B .. E - 1 (the index is a constant expression in the body,
+// whatever the unroller would have made of a plain loop)
+template <int B, int E, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (B < E) {
+        f(std::integral_constant<int, B>{});
+        static_for<B + 1, E>(f);
+    }
+}
 
 constexpr int kGwStage = 2 * 256 * 64;  // bytes per sub-step buffer
 
@@ -554,7 +566,10 @@ __global__ __launch_bounds__(256, 1) void dense_scores_256r16(const _Float16* __
 // (see dense_scores_256r16); the issue order is pinned with sched_barrier(0).
 constexpr int kGkStage = 2 * 256 * 128;  // bytes per 64-deep step buffer: A rows then B rows
 
-template <int LAB = 0>
+constexpr int kGkBarrierAt = 39;   // the step's barrier follows this MFMA (the 16 fragment reads of buffer `cur` end at MFMA 31)
+constexpr int kGkStoreEvery = 5;   // 16 staged stores, one per this many MFMAs, after the barrier (16 x 5 = 80 <= 88)
+
+template <int LAB = 0, int ADEPTH = 1>  // ADEPTH 2: a second staging set for the A operand (loads two steps ahead): measured no gain
 __global__ __launch_bounds__(256, 1) void dense_scores_256k(const _Float16* __restrict__ Q, const _Float16* __restrict__ P,
                                                             uint32_t* __restrict__ out, uint32_t M, uint32_t N, uint32_t H,
                                                             uint64_t ld, uint32_t qb_n, uint32_t db_n, uint32_t raw) {
@@ -590,7 +605,7 @@ __global__ __launch_bounds__(256, 1) void dense_scores_256k(const _Float16* __re
     const uint32_t loff = srow * 128 + (sseg ^ ((srow >> 1) & 7)) * 16;
     const uint64_t gstep = (uint64_t)32 * H * 2;  // 32 rows further
     const uint32_t KS = H / 64;
-    u32x4 ra[8], rb[8];
+    u32x4 ra[8], rb[8], ra2[ADEPTH == 2 ? 8 : 1];
     auto gload_all = [&](uint32_t S) {
         const uint64_t k0 = (uint64_t)min(S, KS - 1) * 128;
 #pragma unroll
@@ -616,7 +631,17 @@ __global__ __launch_bounds__(256, 1) void dense_scores_256k(const _Float16* __re
     lstore_all(0);
     gload_all(1);
     lstore_all(1);
-    gload_all(2);
+    if constexpr (ADEPTH == 2) {  // (the loop's order of requests: A of step 2, A of step 3, B of step 2)
+        const uint64_t k2 = (uint64_t)min(2u, KS - 1) * 128, k3 = (uint64_t)min(3u, KS - 1) * 128;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) ra[i] = *reinterpret_cast<const u32x4*>(qbase + k2 + i * gstep + goff);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) ra2[i] = *reinterpret_cast<const u32x4*>(qbase + k3 + i * gstep + goff);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) rb[i] = *reinterpret_cast<const u32x4*>(pbase + k2 + i * gstep + goff);
+    } else {
+        gload_all(2);
+    }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     bar();
 #pragma unroll
@@ -627,54 +652,65 @@ __global__ __launch_bounds__(256, 1) void dense_scores_256k(const _Float16* __re
     uint64_t t0 = 0, r0 = 0;
     if constexpr (LAB == 3) t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
     uint64_t lap0 = 0, lap1 = 0, lap2 = 0;
-    for (uint32_t S = 0; S < KS; ++S) {
+    // one 64-deep step; raS holds the A operand of step S + 2 and is refilled with step S + 1 + a_ahead
+    auto do_step = [&](uint32_t S, u32x4 (&raS)[8]) {
+        constexpr uint32_t a_ahead = ADEPTH == 2 ? 4 : 3;
         uint64_t s0 = 0, s1 = 0, s2 = 0;
         if constexpr (LAB >= 5) s0 = __builtin_amdgcn_s_memtime();
         const uint8_t* const cur = smem + (S & 1) * kGkStage;
         const uint8_t* const oth = smem + ((S & 1) ^ 1) * kGkStage;
         uint8_t* const curw = smem + (S & 1) * kGkStage;
-        // ---- half 0
-#pragma unroll
-        for (int m = 0; m < 64; ++m) {
-            const int i = m >> 3, j = m & 7;
-            asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(acc[i][j]) : "v"(xa[i]), "v"(xb[j]));
-            if (m < 32 && (m & 1)) {
-                const int q = m >> 1;
-                if (q < 8) yb[q] = *reinterpret_cast<const half8*>(cur + fb + q * 16 * 128 + fs1);
+        const uint64_t k0 = (uint64_t)min(S + 3, KS - 1) * 128, k0a = (uint64_t)min(S + a_ahead, KS - 1) * 128;
+        // 128 MFMAs: 0-63 on the k-half-0 fragments (xa, xb), 64-127 on the k-half-1 fragments (ya, yb)
+        static_for<0, 128>([&](auto mc) {
+            constexpr int m = decltype(mc)::value;
+            constexpr int i = (m & 63) >> 3, j = m & 7;
+            if constexpr (m < 64) asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(acc[i][j]) : "v"(xa[i]), "v"(xb[j]));
+            else asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(acc[i][j]) : "v"(ya[i]), "v"(yb[j]));
+            if constexpr (m < 32 && (m & 1)) {  // the k-half-1 fragments of this step
+                constexpr int q = m >> 1;
+                if constexpr (q < 8) yb[q] = *reinterpret_cast<const half8*>(cur + fb + q * 16 * 128 + fs1);
                 else ya[q - 8] = *reinterpret_cast<const half8*>(cur + fa + (q - 8) * 16 * 128 + fs1);
             }
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        if constexpr (LAB >= 5) s1 = __builtin_amdgcn_s_memtime();
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        bar();
-        if constexpr (LAB >= 5) s2 = __builtin_amdgcn_s_memtime();
-        // ---- half 1
-        const uint64_t k0 = (uint64_t)min(S + 3, KS - 1) * 128;
-#pragma unroll
-        for (int m = 0; m < 64; ++m) {
-            const int i = m >> 3, j = m & 7;
-            asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(acc[i][j]) : "v"(ya[i]), "v"(yb[j]));
-            if (m < 32 && (m & 1)) {
-                const int q = m >> 1;  // a fragment read of the next step per second MFMA
-                if (q < 8) xb[q] = *reinterpret_cast<const half8*>(oth + fb + q * 16 * 128 + fs0);
-                else xa[q - 8] = *reinterpret_cast<const half8*>(oth + fa + (q - 8) * 16 * 128 + fs0);
+            if constexpr (m == kGkBarrierAt) {  // every wave has read all it needs from buffer `cur`; step S + 1 is complete in `oth`
+                if constexpr (LAB >= 5) s1 = __builtin_amdgcn_s_memtime();
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                bar();
+                if constexpr (LAB >= 5) s2 = __builtin_amdgcn_s_memtime();
             }
-            if ((m & 3) == 2) {
-                // a staged store per fourth MFMA (the LDS store path moves ~79 B/clk for the whole CU: packed more
-                // densely the stores stall their waves), each followed by the load that refills its registers
-                const int q = m >> 2;
-                if (q < 8) {
-                    if constexpr (LAB != 7) *reinterpret_cast<u32x4*>(curw + loff + q * 32 * 128) = ra[q];
-                    if constexpr (LAB != 6) ra[q] = *reinterpret_cast<const u32x4*>(qbase + k0 + q * gstep + goff);
+            if constexpr (m > kGkBarrierAt && (m - kGkBarrierAt - 1) % kGkStoreEvery == kGkStoreEvery / 2 &&
+                          (m - kGkBarrierAt - 1) / kGkStoreEvery < 16) {
+                // a staged store of step S + 2 every kGkStoreEvery-th MFMA (the LDS store path moves ~79 B/clk for the
+                // whole CU: packed densely the stores stall their waves), each followed by the load that refills its
+                // registers with step S + 3
+                constexpr int q = (m - kGkBarrierAt - 1) / kGkStoreEvery;
+                if constexpr (q < 8) {
+                    if constexpr (LAB != 7) *reinterpret_cast<u32x4*>(curw + loff + q * 32 * 128) = raS[q];
+                    if constexpr (LAB != 6) raS[q] = *reinterpret_cast<const u32x4*>(qbase + k0a + q * gstep + goff);
                 } else {
                     if constexpr (LAB != 7) *reinterpret_cast<u32x4*>(curw + 256 * 128 + loff + (q - 8) * 32 * 128) = rb[q - 8];
                     if constexpr (LAB != 6) rb[q - 8] = *reinterpret_cast<const u32x4*>(pbase + k0 + (q - 8) * gstep + goff);
                 }
             }
+            if constexpr (m >= 64 && m < 96 && (m & 1)) {  // the k-half-0 fragments of the next step
+                constexpr int q = (m - 64) >> 1;
+                if constexpr (q < 8) xb[q] = *reinterpret_cast<const half8*>(oth + fb + q * 16 * 128 + fs0);
+                else xa[q - 8] = *reinterpret_cast<const half8*>(oth + fa + (q - 8) * 16 * 128 + fs0);
+            }
             __builtin_amdgcn_sched_barrier(0);
-        }
+        });
         if constexpr (LAB >= 5) lap0 += s1 - s0, lap1 += s2 - s1, lap2 += __builtin_amdgcn_s_memtime() - s2;
+    };
+    if constexpr (ADEPTH == 2) {
+#pragma nounroll
+        for (uint32_t S = 0; S + 1 < KS; S += 2) {
+            do_step(S, ra);
+            do_step(S + 1, ra2);
+        }
+        if (KS & 1) do_step(KS - 1, ra);
+    } else {
+#pragma nounroll
+        for (uint32_t S = 0; S < KS; ++S) do_step(S, ra);
     }
     if constexpr (LAB >= 5)
         if (tid == 0 && blockIdx.x < 4096)

@@ -85,7 +85,8 @@ int main(int argc, char** argv) {
     CK(hipStreamCreate(&st));
     float ms = 0;
     const int lab = argc > 6 ? atoi(argv[6]) : 0;
-    int rc = nbuf == 64 ? run_kernel(lab == 3 ? dense_scores_256k<3> : lab == 5 ? dense_scores_256k<5> : lab == 6 ? dense_scores_256k<6> : lab == 7 ? dense_scores_256k<7> : dense_scores_256k<0>, 2 * kGkStage, dq, dp, dout, M, N, H, ld, reps, st, &ms)
+    int rc = nbuf == 642 ? run_kernel(lab == 5 ? dense_scores_256k<5, 2> : dense_scores_256k<0, 2>, 2 * kGkStage, dq, dp, dout, M, N, H, ld, reps, st, &ms)
+             : nbuf == 64 ? run_kernel(lab == 3 ? dense_scores_256k<3> : lab == 5 ? dense_scores_256k<5> : lab == 6 ? dense_scores_256k<6> : lab == 7 ? dense_scores_256k<7> : dense_scores_256k<0>, 2 * kGkStage, dq, dp, dout, M, N, H, ld, reps, st, &ms)
              : nbuf == 16 ? run_kernel(lab == 3 ? dense_scores_256r16<3> : dense_scores_256r16<0>, 2 * kGwStage, dq, dp, dout, M, N, H, ld, reps, st, &ms)
              : nbuf == 2 ? run_kernel(lab == 1 ? dense_scores_256r<1> : lab == 3 ? dense_scores_256r<3> : lab == 4 ? dense_scores_256r<4> : dense_scores_256r<0>, 2 * kGwStage, dq, dp, dout, M, N, H, ld, reps, st, &ms)
              : lab == 3 ? run<4, 3>(dq, dp, dout, M, N, H, ld, reps, st, &ms)
@@ -102,7 +103,7 @@ int main(int argc, char** argv) {
             if (stamps[8 * b]) l0.push_back(stamps[8 * b] / (H / 64.0)), l1.push_back(stamps[8 * b + 1] / (H / 64.0)), l2.push_back(stamps[8 * b + 2] / (H / 64.0));
         std::sort(l0.begin(), l0.end()), std::sort(l1.begin(), l1.end()), std::sort(l2.begin(), l2.end());
         if (!l0.empty())
-            printf("laps per 64-deep step (median cycles): half 0 %.0f, wait + barrier %.0f, half 1 %.0f (1024 per half = MFMA-bound)\n", l0[l0.size() / 2],
+            printf("laps per 64-deep step (median cycles): before the barrier %.0f, wait + barrier %.0f, after %.0f (2048 in all = MFMA-bound)\n", l0[l0.size() / 2],
                    l1[l1.size() / 2], l2[l2.size() / 2]);
     }
     if (lab == 3 || lab == 4) {  // stamps of the last launch: K-loop cycles per 32-deep sub-step, in-kernel clock, block lives

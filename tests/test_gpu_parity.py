@@ -565,9 +565,11 @@ def _unit_rows(rng, n, h):
 _dense_oracle = helpers.dense_oracle
 
 
-# (the third-last case fills >= 256 blocks of 256 x 256: the LDS-DMA GEMM kernel; the others take the 128 x 128 one)
+# (the last three cases fill >= 256 blocks of 256 x 256: the four-wave 16x16x32 GEMM kernel with 1, 2 and 3 steps of 64
+# in K, a doc count that is not a multiple of the 4-doc store width, ragged last blocks in both directions; the others
+# take the 128 x 128 kernel)
 @pytest.mark.parametrize("n,h,nq,k", [(5000, 256, 300, 1000), (700, 64, 130, 10), (20000, 128, 64, 100), (3, 16, 5, 10),
-                                      (4200, 192, 4100, 10), (9000, 64, 2100, 100)])
+                                      (4200, 192, 4100, 10), (9000, 64, 2100, 100), (4203, 128, 4100, 10)])
 def test_dense_search_against_numpy(m, n, h, nq, k):
     from mllm_sparse_retrieval_amd.dense import FaissFlatSearcher
 
