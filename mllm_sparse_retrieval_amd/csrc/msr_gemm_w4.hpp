@@ -509,7 +509,14 @@ __global__ __launch_bounds__(256, 1) void dense_scores_256r16(const _Float16* __
             g_gemm_lab_stamps[8 * blockIdx.x] = t1 - t0, g_gemm_lab_stamps[8 * blockIdx.x + 1] = r1 - r0, g_gemm_lab_stamps[8 * blockIdx.x + 4] = r0,
             g_gemm_lab_stamps[8 * blockIdx.x + 5] = r1;
     }
-    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");  // the last MFMAs' results before any accvgpr read (hazard not seen through asm)
+    // The compiler does not know the asm statements are MFMAs: their write -> accvgpr-read hazard is covered by hand.
+    // The empty asms tie every accumulator to a point AFTER the nops (volatile asms keep their order), so that no read
+    // of a result can be scheduled above them.
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) asm volatile("" : "+a"(acc[i][j]));
     // ---- epilogue through LDS (see store_block_via_lds): pass t carries the tile rows i = 2t, 2t + 1 of every wave:
     // 64 query rows (2 wave rows x 32) x 256 docs
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
@@ -718,10 +725,17 @@ __global__ __launch_bounds__(256, 1) void dense_scores_256k(const _Float16* __re
     if constexpr (LAB == 3) {
         const uint64_t t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
         if (tid == 0 && blockIdx.x < 4096)
-            g_gemm_lab_stamps[8 * blockIdx.x] = (t1 - t0) / 2, g_gemm_lab_stamps[8 * blockIdx.x + 1] = (r1 - r0) / 2,
+            g_gemm_lab_stamps[8 * blockIdx.x] = t1 - t0, g_gemm_lab_stamps[8 * blockIdx.x + 1] = r1 - r0,
             g_gemm_lab_stamps[8 * blockIdx.x + 4] = r0, g_gemm_lab_stamps[8 * blockIdx.x + 5] = r1;
     }
-    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");  // the last MFMAs' results before any accvgpr read (hazard not seen through asm)
+    // The compiler does not know the asm statements are MFMAs: their write -> accvgpr-read hazard is covered by hand.
+    // The empty asms tie every accumulator to a point AFTER the nops (volatile asms keep their order), so that no read
+    // of a result can be scheduled above them.
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) asm volatile("" : "+a"(acc[i][j]));
     // ---- epilogue through LDS (see store_block_via_lds): pass t carries the tile rows i = 2t, 2t + 1 of every wave:
     // 64 query rows (2 wave rows x 32) x 256 docs = 64 KiB, alternating between the two step buffers
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
