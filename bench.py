@@ -803,7 +803,7 @@ def run_c5(args, ranks, m):
            "value": round(nq / (kern * 1e-3), 1), "unit": "queries/s (kernel time, inputs resident)",
            "host_inclusive_queries_per_s": round(nq / wall, 1),
            "kernel_ms": kernel_ms,
-           "pipeline": ("dense_scores_256p (fp16 MFMA GEMM on the ordinal-ordered passage matrix, query chunks of ~160 MB "
+           "pipeline": ("dense_scores_256k (fp16 MFMA GEMM, 16x16x32, four waves of 128x128, on the ordinal-ordered passage matrix, query chunks of ~160 MB "
                         "of score rows) -> hybrid_tiles (one workgroup per query: sparse scores in LDS, both depth-"
                         f"{depth} memberships by one histogram pass, min-max fusion, top-{k})") if fused else
                        "list-based: score_tiles + dense GEMM + select_tiles + fuse_tiles + merges (multi-tile index)",

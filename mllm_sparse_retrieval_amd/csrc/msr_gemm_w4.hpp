@@ -634,10 +634,21 @@ __global__ __launch_bounds__(256, 1) void dense_scores_256k(const _Float16* __re
     auto bar = []() { asm volatile("s_barrier" ::: "memory"); };
     half8 xa[8], xb[8], ya[8], yb[8];
     // ---- prologue: steps 0 and 1 into the LDS buffers, step 2 into the staging registers
-    gload_all(0);
-    lstore_all(0);
-    gload_all(1);
-    lstore_all(1);
+    {   // (steps 0 and 1 are requested together — one memory round trip, not two; the extra registers die here)
+        u32x4 ta[8], tb[8];
+        const uint64_t k1 = (uint64_t)min(1u, KS - 1) * 128;
+        gload_all(0);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) ta[i] = *reinterpret_cast<const u32x4*>(qbase + k1 + i * gstep + goff);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) tb[i] = *reinterpret_cast<const u32x4*>(pbase + k1 + i * gstep + goff);
+        lstore_all(0);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            *reinterpret_cast<u32x4*>(smem + kGkStage + loff + i * 32 * 128) = ta[i];
+            *reinterpret_cast<u32x4*>(smem + kGkStage + 256 * 128 + loff + i * 32 * 128) = tb[i];
+        }
+    }
     if constexpr (ADEPTH == 2) {  // (the loop's order of requests: A of step 2, A of step 3, B of step 2)
         const uint64_t k2 = (uint64_t)min(2u, KS - 1) * 128, k3 = (uint64_t)min(3u, KS - 1) * 128;
 #pragma unroll
