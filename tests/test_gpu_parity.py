@@ -50,6 +50,35 @@ def test_flickr_shape_c2(m, tmp_path):
     _case(m, tmp_path, 1000, 128, 5000, 12, 32064, seed=1, tile_docs=0, ks=[10])
 
 
+def test_flickr_headline_full_shape(m, tmp_path):
+    # The bench's headline workload at its real size (BASELINE configs 1/2 on the whole Flickr30K: 31 014 image docs x
+    # 128 nnz, ALL 155 070 caption queries of 8-15 terms, V = 32 064, top-10, default tile): every query against the C
+    # oracle, through the resident batch the bench times and through one msr_search_csr call (threaded normalisation)
+    from mllm_sparse_retrieval_amd import workloads
+
+    wl = workloads.flickr30k_t2i(threads=8)
+    qp, qt, qw = wl.queries
+    assert len(qp) - 1 == 155070
+    path = m.build_index_from_csr(str(tmp_path / "f.idx"), *wl.docs, wl.n_terms, threads=8, tile_docs=0)
+    oix, _ = helpers.taat_oracle(wl.docs, wl.n_terms)
+    want = oix.search(qp, qt, qw, 10, threads=16)
+    with m.SparseIndex(path, device=0) as ix:
+        assert ix.n_tiles == 4 and ix.tile_docs == 8192
+        batch = ix.batch(qp, qt, qw, 10)
+        batch.search(10)
+        batch.search(10)                                   # (a second pass over the resident batch: same result)
+        helpers.assert_same_results(batch.fetch(), want, 10)
+        helpers.assert_same_results(ix.search_csr(qp, qt, qw, 10), want, 10)
+        got = batch.fetch()
+        # Recall@1/5/10 as the bench prints it (qrels: caption j <-> image j // 5): the planted captions make it a
+        # meaningful number — not 0, not trivially 1 at k = 1
+        doc_int = np.array([int(ix.docid(o)) for o in range(ix.n_docs)], dtype=np.int64)
+    ranked = np.where(np.arange(10)[None, :] < got[3][:, None], doc_int[np.minimum(got[0], 31013)], -1)
+    target = (np.arange(155070) // 5)[:, None]
+    r1, r10 = [(ranked[:, :k] == target).any(axis=1).mean() for k in (1, 10)]
+    assert 0.05 < r1 < r10 <= 1.0
+
+
 def test_coco_shape_c3_depth1000(m, tmp_path):
     # COCO-5K t->i shape with the hybrid script's depth 1000 (scripts/search.sh:25): large-k path
     _case(m, tmp_path, 5000, 128, 300, 120, 30000, seed=2, tile_docs=0, ks=[10, 1000])
