@@ -104,15 +104,18 @@ def assert_same_results(got, want, k):
     assert (g_u32[~mask] == 0).all()
 
 
-def dense_oracle(q, p, k):
+def dense_oracle(q, p, k, tie_key=None):
     """numpy f32 inner products of the fp16-ROUNDED inputs (the storage precision of the reference's GPU faiss,
-    src/search.py:257), ranked by (-score, row). Tolerance on scores: 1e-5 (f32 accumulation order)."""
+    src/search.py:257), ranked by (-score, row) — or by (-score, tie_key[row]) when a tie key is given (the fused
+    hybrid kernel breaks exact dense ties by doc ordinal: DESIGN.md §5). Tolerance on scores: 1e-5 (f32 accumulation order)."""
     s = q.astype(np.float16).astype(np.float32) @ p.astype(np.float16).astype(np.float32).T
-    order = np.lexsort((np.broadcast_to(np.arange(s.shape[1]), s.shape), -s), axis=1)[:, :k]
+    tk = np.arange(s.shape[1]) if tie_key is None else np.asarray(tie_key, dtype=np.int64)
+    order = np.lexsort((np.broadcast_to(tk, s.shape), -s), axis=1)[:, :k]
     return np.take_along_axis(s, order, axis=1), order
 
 
-def oracle_hybrid(docs, n_terms, ids, qp, qt, qw, q, p, depth, alpha, sample, remove_query=False, qids=None):
+def oracle_hybrid(docs, n_terms, ids, qp, qt, qw, q, p, depth, alpha, sample, remove_query=False, qids=None,
+                  dense_tie_key=None):
     """The reference's hybrid pipeline driven by the oracles for the queries in `sample`: C oracle sparse top-depth +
     numpy dense top-depth -> oracle.get_run_dict -> oracle.fuse (pinned to src/hybrid.py:32-53).
     -> ({qid: {doc: fused}}, qids of the sample)"""
@@ -127,7 +130,7 @@ def oracle_hybrid(docs, n_terms, ids, qp, qt, qw, q, p, depth, alpha, sample, re
     sq = [str(int(i)) for i in sample] if qids is None else [qids[int(i)] for i in sample]
     o_sparse = oracle.get_run_dict(sq, [[float(np.float32(x)) for x in wsc[j, :wn[j]]] for j in range(len(sample))],
                                    [[sorted_ids[int(d)] for d in wo[j, :wn[j]]] for j in range(len(sample))], remove_query)
-    dsc, didx = dense_oracle(q[sample], p, min(depth, p.shape[0]))
+    dsc, didx = dense_oracle(q[sample], p, min(depth, p.shape[0]), dense_tie_key)
     o_dense = oracle.get_run_dict(sq, dsc, np.array([[ids[j] for j in row] for row in didx]), remove_query)
     return oracle.fuse([o_dense, o_sparse], [alpha, 1 - alpha]), sq
 

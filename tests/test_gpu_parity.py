@@ -805,12 +805,12 @@ def test_fused_hybrid_randomised(m, tmp_path):
     rows (exact dense ties: ids may differ inside a tie, scores may not)."""
     from mllm_sparse_retrieval_amd.dense import DenseIndex, hybrid_search, row_to_ordinal
 
-    rng = np.random.default_rng(20251005)
-    for case in range(14):
+    rng = np.random.default_rng(int(os.environ.get("MSR_FUZZ_SEED", "20251005")))
+    for case in range(int(os.environ.get("MSR_FUZZ_CASES", "14"))):
         n = int(rng.choice([37, 700, 2047, 2049, 4096, 4097, 6000, 8192]))
         n_terms = int(rng.choice([6, 60, 2000]))
         nnz = int(min(n_terms, rng.integers(1, 24)))
-        nq = int(rng.integers(3, 40))
+        nq = min(int(rng.integers(3, 40)), n)                               # (query ids are doc ids: keep them distinct)
         qn = int(min(n_terms, rng.integers(0, 12)))
         depth = int(rng.choice([1, 7, 100, 1000, 1024]))
         k = int(rng.choice([1, 10, 64]))
@@ -820,7 +820,7 @@ def test_fused_hybrid_randomised(m, tmp_path):
         dp = np.arange(0, n * nnz + 1, nnz, dtype=np.uint64)
         dt = np.concatenate([rng.choice(n_terms, nnz, replace=False) for _ in range(n)]).astype(np.uint32)
         dw = rng.integers(1, 300, n * nnz).astype(np.uint32)
-        qp = np.arange(0, nq * qn + 1, qn, dtype=np.int64)
+        qp = np.arange(nq + 1, dtype=np.int64) * qn                         # (qn may be 0: empty queries)
         qt = rng.integers(0, n_terms, nq * qn).astype(np.int32)
         qw = rng.integers(0, 50, nq * qn).astype(np.int32)
         ids = [str(int(x)) for x in rng.permutation(n * 3)[:n]]            # ids in no particular order
@@ -838,9 +838,18 @@ def test_fused_hybrid_randomised(m, tmp_path):
             ords, fs, cnt, ms = hybrid_search(ix, dix, qp, qt, qw, q, depth, k, alpha, r2o, self_ord)
             assert ms["fusion"] == 0 and ms["dense_select"] == 0
             docid_of = ix.docid
+            # (exact dense ties — the duplicated rows — go to the lower doc ORDINAL in the fused kernel, to the lower row
+            # in the reference's flat index: the oracle is told the kernel's rule, so that the depth boundary cuts the
+            # same twin on both sides)
             want, sq = helpers.oracle_hybrid((dp, dt, dw), n_terms, ids, qp, qt, qw, q, p, depth, alpha, np.arange(nq),
-                                             remove, qids)
+                                             remove, qids, dense_tie_key=r2o)
+            # min-max normalisation divides by the spread of the top-depth list: the f32 accumulation-order noise of the
+            # raw dense scores (a few 1e-7 at these dimensions; the 1e-5 of the north star is the bound on RAW scores)
+            # reaches the fused score multiplied by alpha / spread — a small depth on a large corpus has a small spread
+            dsc_o, _ = helpers.dense_oracle(q, p, min(depth, n), r2o)
+            spread = np.maximum(dsc_o[:, 0] - dsc_o[:, -1], 1e-3)
             for i in range(nq):
+                tol = 1e-5 + alpha * 1e-6 / float(spread[i])
                 ranked = sorted(want[sq[i]].items(), key=lambda kv: (-float(kv[1]), kv[0].encode()))[:k]
                 assert cnt[i] == len(ranked), (case, i, cnt[i], len(ranked))
                 got = [docid_of(int(o)) for o in ords[i, : cnt[i]]]
@@ -848,7 +857,7 @@ def test_fused_hybrid_randomised(m, tmp_path):
                 for r, (doc, score) in enumerate(ranked):
                     # scores position by position (a dense tie at the depth boundary may admit the twin row instead:
                     # the same score then sits on another id)
-                    assert abs(float(fs[i, r]) - float(score)) <= 1e-5, (case, i, r, float(fs[i, r]), float(score))
+                    assert abs(float(fs[i, r]) - float(score)) <= tol, (case, i, r, float(fs[i, r]), float(score), tol)
                 if remove:
                     assert qids[i] not in got
             dix.close()
@@ -904,8 +913,9 @@ def test_fused_hybrid_mass_ties(m, tmp_path):
 def test_randomised_configurations(m, tmp_path):
     """Fuzz: random corpus shapes, vocabularies, weights (including the 65 535 maximum), tile sizes, dense-head
     options, query shapes (OOV, zero weights, repeats) and k, each against the C oracle."""
-    rng = np.random.default_rng(20250418)
-    for case in range(24):
+    # (MSR_FUZZ_SEED / MSR_FUZZ_CASES: longer sessions with other seeds, scripts/gpu_fuzz.sh)
+    rng = np.random.default_rng(int(os.environ.get("MSR_FUZZ_SEED", "20250418")))
+    for case in range(int(os.environ.get("MSR_FUZZ_CASES", "24"))):
         n_docs = int(rng.integers(1, 20000))
         n_terms = int(rng.integers(1, 400))
         nnz = int(rng.integers(1, min(n_terms, 40) + 1))
