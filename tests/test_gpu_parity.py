@@ -606,7 +606,8 @@ def test_dense_search_against_numpy(m, n, h, nq, k):
     p, q = _unit_rows(rng, n, h), _unit_rows(rng, nq, h)
     r = FaissFlatSearcher(p)
     r.add(p)
-    scores, idx = r.batch_search(q, k, batch_size=97, quiet=True)
+    # (batch_search issues one GPU call per batch: the big cases go in one call, the others in ragged batches of 97)
+    scores, idx = r.batch_search(q, k, batch_size=nq if nq >= 2000 else 97, quiet=True)
     ws, wi = _dense_oracle(q, p, min(k, n))
     kk = min(k, n)
     assert np.abs(scores[:, :kk] - ws).max() <= 1e-5
@@ -618,6 +619,33 @@ def test_dense_search_against_numpy(m, n, h, nq, k):
                                              @ p.astype(np.float16).astype(np.float32).T, idx[:, :kk], axis=1))
         assert gap[diff].max() <= 2e-6 and diff.mean() < 0.01
     assert (np.diff(scores[:, :kk], axis=1) <= 0).all()
+
+
+def test_dense_gemm_random_shapes(m):
+    """The four-wave GEMM kernel (grids of >= 256 blocks of 256 x 256) on random shapes: ragged last blocks in both
+    directions, 1-8 steps of 64 in K, doc counts that are not multiples of 4; scores within 1e-5 of numpy on the
+    fp16-rounded inputs, ranks equal except inside accumulation-noise ties. (MSR_FUZZ_SEED / MSR_FUZZ_CASES as above.)"""
+    from mllm_sparse_retrieval_amd.dense import FaissFlatSearcher
+
+    rng = np.random.default_rng(int(os.environ.get("MSR_FUZZ_SEED", "7")))
+    for case in range(int(os.environ.get("MSR_FUZZ_CASES", "4"))):
+        h = 64 * int(rng.integers(1, 9))
+        n = int(rng.integers(4100, 7000))
+        nq = int(rng.integers(max(4100, (256 * 256 * 256) // ((n + 255) // 256 * 256) + 1), 7000))
+        k = int(rng.choice([1, 10, 100]))
+        assert ((n + 255) // 256) * ((nq + 255) // 256) >= 256
+        p, q = _unit_rows(rng, n, h), _unit_rows(rng, nq, h)
+        r = FaissFlatSearcher(p)
+        r.add(p)
+        scores, idx = r.batch_search(q, k, batch_size=nq, quiet=True)         # ONE call: the grid is the whole product
+        ws, wi = _dense_oracle(q, p, k)
+        assert np.abs(scores - ws).max() <= 1e-5, (case, n, h, nq, k)
+        diff = idx != wi
+        if diff.any():
+            exact = q.astype(np.float16).astype(np.float32) @ p.astype(np.float16).astype(np.float32).T
+            gap = np.abs(ws - np.take_along_axis(exact, idx, axis=1))
+            assert gap[diff].max() <= 2e-6 and diff.mean() < 0.01, (case, n, h, nq, k)
+        del r
 
 
 def test_hybrid_fusion_end_to_end(m, tmp_path):
