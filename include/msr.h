@@ -206,6 +206,11 @@ int msr_dense_open(const uint16_t* p_fp16, uint64_t n, uint32_t h, int device, m
 int msr_dense_search(msr_dense* dx, const uint16_t* q_fp16, int nq, int k, uint32_t* out_idx, uint32_t* out_key,
                      int32_t* out_n, float* gemm_ms, float* select_ms);
 void msr_dense_close(msr_dense* dx);
+/* Host helper for the two calls above: n f32 values -> IEEE fp16, round to nearest even (what numpy's astype(float16)
+ * and the reference's .half() produce: src/search.py:257), on `threads` host threads (<= 0: all). The reference hands
+ * its query matrix over in f32 (src/search.py:342-343); converting 25 010 x 4 096 values in numpy takes longer than
+ * the whole GPU search. */
+int msr_f32_to_f16(const float* src, uint16_t* dst, uint64_t n, int threads);
 
 /* ---- hybrid search on the GPU: sparse top-`depth` + dense top-`depth` + the reference's min-max fusion
  * (fuse, src/hybrid.py:32-53, weights [alpha, 1-alpha] src/search.py:459) + top-k, without leaving HBM in between.

@@ -85,6 +85,7 @@ SYMBOLS = [
     ("msr_dense_open", _I, [_VP, _U64, _U32, _I, C.POINTER(_VP)]),
     ("msr_dense_search", _I, [_VP, _VP, _I, _I, _VP, _VP, _VP, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
     ("msr_dense_close", None, [_VP]),
+    ("msr_f32_to_f16", _I, [_VP, _VP, _U64, _I]),
     ("msr_hybrid_search", _I, [_VP, _VP, _VP, _VP, _VP, _VP, _I, _I, _I, C.c_float, _U32, _VP, _VP, _VP, _VP, _VP, _VP]),
     ("msr_sparsify", _I, [_VP, _I, _I, _I, _U32, _I, _I, _VP, _VP, _VP]),
     ("msr_synth_vectors", _I, [_U64, _U32, _U32, C.c_double, _U64, _I, _VP, _VP, _VP]),

@@ -1,6 +1,8 @@
 // Hybrid path and encode-side sparsifier: the dense fp16 MFMA scorer (dense_scores), the reference's min-max fusion on
 // the GPU (fuse_tiles), the log1p-relu top-k sparsifier (sparsify_keys), and their C-ABI entry points. Selection and
 // list merging reuse the search path's kernels (launch_select / launch_merge, msr_device.hip).
+#include <chrono>
+
 #include "msr_accumulate.hpp"
 #include "msr_gemm_w4.hpp"
 
@@ -1224,6 +1226,19 @@ static int hybrid_search_fused(msr_index* ix, msr_dense* dx, const int64_t* q_pt
     const IndexHeader* h = ix->host.h;
     const uint64_t n = h->n_docs;
     HIP_TRY(hipSetDevice(d->device));
+    // diagnostic (MSR_DEBUG_HYBRID): host-side laps of the call, printed with the kernel span
+    static const bool dbg_host = getenv("MSR_DEBUG_HYBRID") != nullptr;
+    auto t_last = std::chrono::steady_clock::now();
+    char laps[512];
+    size_t laps_n = 0;
+    laps[0] = 0;
+    auto lap = [&](const char* what) {
+        if (!dbg_host) return;
+        const auto now = std::chrono::steady_clock::now();
+        const double msx = std::chrono::duration<double, std::milli>(now - t_last).count();
+        t_last = now;
+        if (laps_n < sizeof(laps)) laps_n += (size_t)snprintf(laps + laps_n, sizeof(laps) - laps_n, " %s %.2f", what, msx);
+    };
     // ---- passage rows in ordinal order (cached on the dense handle while the mapping is unchanged)
     if (!dx->d_P_ord || dx->ord_map.size() != n || memcmp(dx->ord_map.data(), row2ord, (size_t)n * 4) != 0) {
         std::vector<uint8_t> seen((size_t)n, 0);
@@ -1258,9 +1273,11 @@ static int hybrid_search_fused(msr_index* ix, msr_dense* dx, const int64_t* q_pt
         }
         dx->ord_map.assign(row2ord, row2ord + n);
     }
+    lap("ordinal map");
     msr_batch* b = nullptr;
     int rc = msr_batch_create(ix, q_ptr, q_term, q_w, nq, k, flags, &b);
     if (rc != MSR_OK) return rc;
+    lap("sparse batch");
     const uint32_t nt_threads = h->tile_docs == 4096 ? 256u : 512u;
     const uint64_t ld = (n + 4 * nt_threads - 1) / (4 * nt_threads) * (4 * nt_threads);  // whole select rounds
     const uint64_t n_cover = std::min<uint64_t>(dx->n_pad, (n + 255) / 256 * 256);
@@ -1335,6 +1352,7 @@ static int hybrid_search_fused(msr_index* ix, msr_dense* dx, const int64_t* q_pt
     ha.out_score = d_sf;
     ha.out_n = d_n;
     static const bool inner_events = getenv("MSR_HYBRID_NO_INNER_EVENTS") == nullptr;
+    lap("alloc + enqueue uploads");
     hipEvent_t e_all[2] = {nullptr, nullptr};
     if (rc == MSR_OK && (hipEventCreate(&e_all[0]) != hipSuccess || hipEventCreate(&e_all[1]) != hipSuccess)) {
         set_error("hipEventCreate failed");
@@ -1381,6 +1399,7 @@ static int hybrid_search_fused(msr_index* ix, msr_dense* dx, const int64_t* q_pt
     float t_gemm = 0, t_fused = 0, t_all = 0;
     if (rc == MSR_OK) (void)hipEventElapsedTime(&t_all, e_all[0], e_all[1]);
     if (getenv("MSR_DEBUG_HYBRID")) fprintf(stderr, "[msr] hybrid pipeline span %.3f ms (inner events %d)\n", t_all, (int)inner_events);
+    lap("uploads + kernels");
     if (rc == MSR_OK && inner_events) {
         for (size_t i = 0; i + 2 < ev.size(); i += 3) {
             float a = 0, c = 0;
@@ -1396,6 +1415,7 @@ static int hybrid_search_fused(msr_index* ix, msr_dense* dx, const int64_t* q_pt
             rc = MSR_E_HIP;
         }
     }
+    lap("download");
     if (ms) {
         ms[0] = t_fused;
         ms[1] = t_gemm;
@@ -1417,6 +1437,8 @@ static int hybrid_search_fused(msr_index* ix, msr_dense* dx, const int64_t* q_pt
     for (void* p2 : ptrs)
         if (p2) (void)hipFree(p2);
     batch_free(b);
+    lap("free");
+    if (dbg_host) fprintf(stderr, "[msr] hybrid host laps (ms):%s\n", laps);
     return rc;
 }
 

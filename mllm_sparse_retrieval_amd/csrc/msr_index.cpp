@@ -1225,6 +1225,66 @@ void term_bounds(const HostIndex& hx, int G, std::vector<uint32_t>& bounds) {
 }
 }  // namespace msr
 
+// ----------------------------------------------------------------------------------------------- f32 -> fp16 (host)
+// Round to nearest even, as IEEE / numpy / torch .half(): F16C (vcvtps2ph) where the CPU has it, else bit arithmetic.
+#if defined(__x86_64__)
+#include <immintrin.h>
+__attribute__((target("f16c,avx"))) static void f32_to_f16_f16c(const float* src, uint16_t* dst, uint64_t n) {
+    uint64_t i = 0;
+    for (; i + 8 <= n; i += 8)
+        _mm_storeu_si128(reinterpret_cast<__m128i*>(dst + i),
+                         _mm256_cvtps_ph(_mm256_loadu_ps(src + i), _MM_FROUND_TO_NEAREST_INT | _MM_FROUND_NO_EXC));
+    for (; i < n; ++i) {
+        const __m128i h = _mm_cvtps_ph(_mm_set_ss(src[i]), _MM_FROUND_TO_NEAREST_INT | _MM_FROUND_NO_EXC);
+        dst[i] = (uint16_t)_mm_extract_epi16(h, 0);
+    }
+}
+#endif
+static uint16_t f32_to_f16_bits(float f) {
+    uint32_t x;
+    memcpy(&x, &f, 4);
+    const uint32_t sign = (x >> 16) & 0x8000u;
+    x &= 0x7FFFFFFFu;
+    if (x >= 0x7F800000u) return (uint16_t)(sign | 0x7C00u | (x > 0x7F800000u ? 0x0200u | ((x >> 13) & 0x03FFu) : 0u));  // inf / nan
+    if (x >= 0x477FF000u) return (uint16_t)(sign | 0x7C00u);  // rounds to >= 65520: overflow to inf
+    if (x < 0x33000001u) return (uint16_t)sign;               // <= 2^-25: rounds to zero (ties to even)
+    uint32_t mant = (x & 0x007FFFFFu) | 0x00800000u;
+    const int exp = (int)(x >> 23) - 127;
+    int shift = 13;
+    uint32_t he = 0;
+    if (exp < -14) shift += -14 - exp;  // subnormal half: more bits leave
+    else he = (uint32_t)(exp + 15) << 10;
+    const uint32_t rest = mant & ((1u << shift) - 1u), half = 1u << (shift - 1);
+    uint32_t hm = mant >> shift;
+    if (rest > half || (rest == half && (hm & 1u))) ++hm;
+    // (normal: the implicit bit sits at 0x400 and adds one to the exponent field on top of he - 0x400)
+    return (uint16_t)(sign | (exp < -14 ? hm : (he - 0x400u + hm)));
+}
+
+extern "C" int msr_f32_to_f16(const float* src, uint16_t* dst, uint64_t n, int threads) {
+    if ((!src || !dst) && n) {
+        msr::set_error("msr_f32_to_f16: null argument");
+        return MSR_E_INVAL;
+    }
+    bool f16c = false;
+#if defined(__x86_64__)
+    f16c = __builtin_cpu_supports("f16c") && __builtin_cpu_supports("avx") && !getenv("MSR_NO_F16C");
+#endif
+    int nt = msr::clamp_threads(threads);
+    nt = (int)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)std::min(nt, 32), n >> 16));  // >= 64 Ki values per thread
+    msr::parallel_run(nt, [&](int t) {
+        const uint64_t a = n * (uint64_t)t / (uint64_t)nt / 8 * 8, b = t + 1 == nt ? n : n * (uint64_t)(t + 1) / (uint64_t)nt / 8 * 8;
+#if defined(__x86_64__)
+        if (f16c) {
+            f32_to_f16_f16c(src + a, dst + a, b - a);
+            return;
+        }
+#endif
+        for (uint64_t i = a; i < b; ++i) dst[i] = f32_to_f16_bits(src[i]);
+    });
+    return MSR_OK;
+}
+
 extern "C" {
 
 // by_terms = false: doc-range shard (contiguous tile range); true: term-range shard (every tile, own term range)

@@ -25,7 +25,10 @@ def keys_to_f32(keys):
     return out
 
 
-def _as_fp16_rows(x, dim=None):
+def _as_fp16_rows(x, dim=None, holder=None):
+    """[rows, dim] matrix -> C-contiguous fp16 (round to nearest even), columns padded to a multiple of 32.
+    `holder`: an object whose `_q16` attribute keeps the output buffer between calls (a fresh 200 MB array costs more in
+    page faults than the conversion itself)."""
     x = np.asarray(x)
     if x.ndim != 2:
         raise ValueError("expected a [rows, dim] matrix")
@@ -33,7 +36,16 @@ def _as_fp16_rows(x, dim=None):
     pad = (-h) % 32  # the GEMM steps K by 32; zero columns do not change inner products
     if dim is not None and h != dim:
         raise ValueError(f"dimension mismatch: {h} vs {dim}")
-    x16 = x.astype(np.float16)
+    if x.dtype == np.float32 and x.flags.c_contiguous and x.size >= (1 << 16):
+        # (numpy converts ~0.2 G values/s on one core: for a big query matrix that is longer than the GPU search)
+        x16 = getattr(holder, "_q16", None) if holder is not None and not pad else None
+        if x16 is None or x16.shape != x.shape:
+            x16 = np.empty(x.shape, dtype=np.float16)
+            if holder is not None and not pad:
+                holder._q16 = x16
+        check(lib().msr_f32_to_f16(ptr(x), ptr(x16.view(np.uint16)), x.size, 0))
+    else:
+        x16 = x.astype(np.float16)
     if pad:
         x16 = np.concatenate([x16, np.zeros((x16.shape[0], pad), np.float16)], axis=1)
     return np.ascontiguousarray(x16)
@@ -52,7 +64,7 @@ class DenseIndex:
 
     def search(self, q_reps, k):
         """-> (scores float32 [nq,k], indices int64 [nq,k]); rows past the hit count hold (-inf, -1) like faiss."""
-        q16 = _as_fp16_rows(q_reps, self.dim)
+        q16 = _as_fp16_rows(q_reps, self.dim, self)   # (consumed by the synchronous call below)
         nq = q16.shape[0]
         idx = np.empty((nq, k), dtype=np.uint32)
         key = np.empty((nq, k), dtype=np.uint32)
@@ -131,7 +143,7 @@ def hybrid_search(sparse_index, dense_index, q_ptr, q_term, q_w, q_reps, depth, 
     from ._cabi import MSR_F_DROP_DF_EQ_N
 
     q_ptr, q_term, q_w = _cabi.as_csr(q_ptr, q_term, q_w)
-    q16 = _as_fp16_rows(q_reps, dense_index.dim)
+    q16 = _as_fp16_rows(q_reps, dense_index.dim, dense_index)   # (consumed by the synchronous call below)
     nq = len(q_ptr) - 1
     if q16.shape[0] != nq:
         raise ValueError("sparse and dense query counts differ")

@@ -233,3 +233,42 @@ def test_eval_subcommand_true_and_compat_denominator(tmp_path, capsys):
     # the padded repeat is counted twice: compat != true whenever the repeated caption is a hit
     rep = [caps[i] for i in DistributedSampler(range(35), num_replicas=4, rank=3, shuffle=True)][-1]
     assert (sum(per_rank) * 36 - r1 * 35) == pytest.approx(1.0 if hit_at(rep, 1) else 0.0)
+
+
+def test_f32_to_f16_matches_numpy_bit_for_bit(monkeypatch):
+    """msr_f32_to_f16 (the host conversion in front of msr_dense_search / msr_hybrid_search): round to nearest even like
+    numpy's astype(float16) — normal values, ties, the subnormal range, overflow to inf, infinities; NaNs stay NaNs.
+    Both code paths: F16C and the portable bit arithmetic."""
+    from mllm_sparse_retrieval_amd._cabi import check, lib, ptr
+
+    rng = np.random.default_rng(3)
+    special = np.array([0.0, -0.0, 1.0, -1.0, 65504.0, 65519.9, 65520.0, 7e4, -7e4, np.inf, -np.inf, np.nan, 6.1035e-5, 6.0e-5,
+                        5.96e-8, 2.98e-8, 2.9802322e-8, 2.9802326e-8, 1e-10, 0.1, 1.0009765, 1.00048828125, 1.0014648],
+                       dtype=np.float32)
+    anybits = rng.integers(0, 2 ** 32, 400_000, dtype=np.uint64).astype(np.uint32).view(np.float32)
+    # every fp16 value, the midpoints between neighbours (ties) and their f32 neighbours
+    halves = np.arange(0, 0x7C00, dtype=np.uint16).view(np.float16).astype(np.float32)
+    mids = (halves[:-1].astype(np.float64) + halves[1:].astype(np.float64)) / 2
+    ties = np.concatenate([mids.astype(np.float32), np.nextafter(mids.astype(np.float32), np.float32(np.inf)),
+                           np.nextafter(mids.astype(np.float32), np.float32(-np.inf))])
+    x = np.concatenate([special, anybits, halves, ties, -ties, rng.standard_normal(200_000).astype(np.float32)])
+    with np.errstate(all="ignore"):
+        want = x.astype(np.float16)
+    for no_f16c in (False, True):
+        if no_f16c:
+            monkeypatch.setenv("MSR_NO_F16C", "1")
+        for threads in (1, 0):
+            got = np.empty(x.shape, dtype=np.float16)
+            check(lib().msr_f32_to_f16(ptr(x), ptr(got.view(np.uint16)), x.size, threads))
+            nan = np.isnan(want)
+            assert (np.isnan(got) == nan).all()
+            assert (got.view(np.uint16)[~nan] == want.view(np.uint16)[~nan]).all(), (no_f16c, threads)
+    # the wrapper takes the C path for big f32 matrices and numpy otherwise: same bits
+    from mllm_sparse_retrieval_amd.dense import _as_fp16_rows
+
+    big = rng.standard_normal((300, 256)).astype(np.float32)
+    assert (_as_fp16_rows(big).view(np.uint16) == big.astype(np.float16).view(np.uint16)).all()
+    odd = rng.standard_normal((300, 250)).astype(np.float32)          # padded to 256 columns
+    out = _as_fp16_rows(odd)
+    assert out.shape == (300, 256) and (out[:, 250:] == 0).all()
+    assert (out[:, :250].view(np.uint16) == odd.astype(np.float16).view(np.uint16)).all()
