@@ -378,6 +378,22 @@ struct msr_dense {
     _Float16* d_P_ord = nullptr;
     std::vector<uint32_t> ord_map;
     bool lds_attr_set = false;  // dense_scores_256 needs the 128 KiB dynamic-LDS opt-in once per device
+    // device scratch of the fused hybrid call (query matrix, score rows, result lists), kept between calls and only ever
+    // grown: six hipMalloc / hipFree pairs of up to 200 MB cost a call more than its kernels
+    void* scratch[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    size_t scratch_bytes[6] = {0, 0, 0, 0, 0, 0};
+    void* take(int slot, size_t bytes) {
+        if (scratch_bytes[slot] >= bytes && scratch[slot]) return scratch[slot];
+        if (scratch[slot]) (void)hipFree(scratch[slot]);
+        scratch[slot] = nullptr;
+        scratch_bytes[slot] = 0;
+        if (hipMalloc(&scratch[slot], bytes) != hipSuccess) {
+            scratch[slot] = nullptr;
+            return nullptr;
+        }
+        scratch_bytes[slot] = bytes;
+        return scratch[slot];
+    }
 };
 
 extern "C" {
@@ -428,6 +444,8 @@ void msr_dense_close(msr_dense* dx) {
     (void)hipSetDevice(dx->device);
     if (dx->d_P_ord) (void)hipFree(dx->d_P_ord);
     if (dx->d_P) (void)hipFree(dx->d_P);
+    for (void* p : dx->scratch)
+        if (p) (void)hipFree(p);
     if (dx->stream) (void)hipStreamDestroy(dx->stream);
     delete dx;
 }
@@ -1302,11 +1320,14 @@ static int hybrid_search_fused(msr_index* ix, msr_dense* dx, const int64_t* q_pt
     if (getenv("MSR_DEBUG_HYBRID") && hipMalloc(&d_stamps, 8 * sizeof(unsigned long long)) == hipSuccess)
         (void)hipMemsetAsync(d_stamps, 0, 8 * sizeof(unsigned long long), d->stream);
     const size_t perk = std::max<size_t>((size_t)nq * k, 1);
-    bool ok = hipMalloc(&d_Q, std::max<size_t>((size_t)nq_pad * dx->h * 2, 16)) == hipSuccess &&
-              hipMalloc(&d_S, (size_t)qc * ld * 4) == hipSuccess && hipMalloc(&d_ord, perk * 4) == hipSuccess &&
-              hipMalloc(&d_sf, perk * 4) == hipSuccess && hipMalloc(&d_n, std::max<size_t>(nq, 1) * 4) == hipSuccess;
+    d_Q = (_Float16*)dx->take(0, std::max<size_t>((size_t)nq_pad * dx->h * 2, 16));
+    d_S = (uint32_t*)dx->take(1, (size_t)qc * ld * 4);
+    d_ord = (uint32_t*)dx->take(2, perk * 4);
+    d_sf = (float*)dx->take(3, perk * 4);
+    d_n = (int32_t*)dx->take(4, std::max<size_t>(nq, 1) * 4);
+    bool ok = d_Q && d_S && d_ord && d_sf && d_n;
     if (ok && self_ord)
-        ok = hipMalloc(&d_self, std::max<size_t>(nq, 1) * 4) == hipSuccess &&
+        ok = (d_self = (int32_t*)dx->take(5, std::max<size_t>(nq, 1) * 4)) != nullptr &&
              hipMemcpyAsync(d_self, self_ord, (size_t)nq * 4, hipMemcpyHostToDevice, d->stream) == hipSuccess;
     if (ok && nq)
         ok = hipMemsetAsync(d_Q + (size_t)nq * dx->h, 0, (size_t)(nq_pad - nq) * dx->h * 2, d->stream) == hipSuccess &&
@@ -1433,9 +1454,7 @@ static int hybrid_search_fused(msr_index* ix, msr_dense* dx, const int64_t* q_pt
         if (x) (void)hipEventDestroy(x);
     for (hipEvent_t x : e_all)
         if (x) (void)hipEventDestroy(x);
-    void* ptrs[] = {d_Q, d_S, d_ord, d_sf, d_n, d_self};
-    for (void* p2 : ptrs)
-        if (p2) (void)hipFree(p2);
+    // (d_Q, d_S, d_ord, d_sf, d_n, d_self stay with the dense handle for the next call)
     batch_free(b);
     lap("free");
     if (dbg_host) fprintf(stderr, "[msr] hybrid host laps (ms):%s\n", laps);
