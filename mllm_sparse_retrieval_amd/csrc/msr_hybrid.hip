@@ -1,6 +1,8 @@
-// Hybrid path and encode-side sparsifier: the dense fp16 MFMA scorer (dense_scores), the reference's min-max fusion on
-// the GPU (fuse_tiles), the log1p-relu top-k sparsifier (sparsify_keys), and their C-ABI entry points. Selection and
-// list merging reuse the search path's kernels (launch_select / launch_merge, msr_device.hip).
+// Hybrid path and encode-side sparsifier: the dense fp16 MFMA scorers (the production 256 x 256 kernel lives in
+// msr_gemm_w4.hpp: dense_scores_256k; here the 128 x 128 kernel for small grids and two earlier 256 x 256 kernels kept
+// as diagnostics), the fused per-query kernel of single-tile indexes (hybrid_tiles), the reference's min-max fusion
+// for multi-tile indexes (fuse_tiles), the log1p-relu top-k sparsifier (sparsify_keys), and their C-ABI entry points.
+// Selection and list merging reuse the search path's kernels (launch_select / launch_merge, msr_device.hip).
 #include <chrono>
 
 #include "msr_accumulate.hpp"
@@ -106,7 +108,7 @@ __global__ __launch_bounds__(256) void dense_scores(const _Float16* __restrict__
 }
 
 
-// ---- the same product on a 256 x 256 block: 8 waves (2 x 4), each 128 x 64 = 4 x 2 MFMA tiles of 32 x 32 (six fragment
+// ---- (diagnostic, MSR_GEMM_NO_PIPE) the same product on a 256 x 256 block: 8 waves (2 x 4), each 128 x 64 = 4 x 2 MFMA tiles of 32 x 32 (six fragment
 // reads per eight MFMAs instead of four per four), K in steps of 64, two LDS stages of 2 x 32 KiB filled by LDS-DMA
 // (global_load_lds_dwordx4: no staging registers, no ds_write pass), one barrier per K step. The DMA writes LDS
 // lane-linear (wave-uniform base + 16 B x lane: eight 128-byte rows per instruction), so the bank swizzle goes on the
@@ -212,7 +214,7 @@ __global__ __launch_bounds__(512, 1) void dense_scores_256(const _Float16* __res
         }
 }
 
-// ---- the same 256 x 256 block with a DEEPER staging pipeline: K in sub-steps of 32 through FOUR LDS buffers of 32 KiB
+// ---- (diagnostic since dense_scores_256k, MSR_GEMM_PINGPONG) the same 256 x 256 block with a DEEPER staging pipeline: K in sub-steps of 32 through FOUR LDS buffers of 32 KiB
 // (A: 256 rows x 64 B, B likewise), three sub-steps of LDS-DMA in flight while the fourth is consumed. The 2-buffer
 // kernel above drains its DMA with vmcnt(0) at every barrier and issues a whole K step's 8 DMAs per wave up front — at
 // 100-185 cycles of issue each that is ~1 200 cycles per wave and step during which neither wave of the SIMD feeds the
