@@ -2,7 +2,7 @@
 // checks a sample of the scores against a plain per-element dot product computed on the device in f32, and times it
 // with HIP events. Diagnostic only (scripts/gpu_gemm_lab.sh builds and runs it on the GPU box).
 #define MSR_GEMM_LAB 1
-#include "../mllm_sparse_retrieval_amd/csrc/msr_gemm_w4.hpp"
+#include "gemm_lab_kernels.hpp"
 
 #include <algorithm>
 #include <cstdio>
