@@ -981,6 +981,29 @@ def test_randomised_configurations(m, tmp_path):
                             ix.search_csr(qp, qt, qw, k, drop_df_eq_n=drop)
                         continue
                     helpers.assert_same_results(ix.search_csr(qp, qt, qw, k, drop_df_eq_n=drop), want, k)
+            # the multi-GPU partitions of the same index, played on this one GPU: doc-range shards + the exact merge,
+            # and term-range shard handles (each resident with its own term range only) + the reduction protocol
+            k = int(rng.integers(1, 64))
+            try:
+                want = oix.search(qp, qt, qw, k, threads=4)
+            except OverflowError:
+                want = None
+            if want is not None:
+                G = int(rng.integers(1, min(ix.n_tiles, 4) + 1))
+                lists = []
+                for sh_i in range(G):
+                    with m.SparseIndex(path, device=0, shard=sh_i, n_shards=G) as sh:
+                        lists.append(sh.search_csr(qp, qt, qw, k))
+                merged = ix.merge_lists(np.stack([l[0] for l in lists]), np.stack([l[2] for l in lists]),
+                                        np.stack([l[3] for l in lists]), k)
+                helpers.assert_same_results(merged, want, k)
+                GT = int(rng.integers(1, 5))
+                shards = [m.SparseIndex(path, device=0, term_shard=(g, GT)) for g in range(GT)]
+                try:
+                    helpers.assert_same_results(m.search_termshard_emulated_handles(shards, qp, qt, qw, k), want, k)
+                finally:
+                    for sh in shards:
+                        sh.close()
         os.remove(path)
 
 
