@@ -272,3 +272,53 @@ def test_f32_to_f16_matches_numpy_bit_for_bit(monkeypatch):
     out = _as_fp16_rows(odd)
     assert out.shape == (300, 256) and (out[:, 250:] == 0).all()
     assert (out[:, :250].view(np.uint16) == odd.astype(np.float16).view(np.uint16)).all()
+
+
+def test_recall_metrics_against_the_reference_class():
+    """recall.RecallMetrics / replay_ranks against outputs of the reference's own RecallMetrics (src/metrices.py),
+    recorded by tests/golden/make_recall_golden.py for world sizes 1 and 2 (gloo): hit counts, every rank's fractions
+    with the reference's padded denominator, the sampler's split, and the text rank 0 prints — bit for bit."""
+    import contextlib
+    import io
+    from types import SimpleNamespace
+
+    from mllm_sparse_retrieval_amd.recall import RecallMetrics, replay_ranks
+    from mllm_sparse_retrieval_amd.sampler import shard_query_ids
+
+    class Stub:
+        def __init__(self, targets):
+            self.targets = targets
+
+        def get_target(self, qid, query_type):
+            return self.targets[qid]
+
+    gold = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "recall_golden.json")))
+    assert len(gold["cases"]) >= 4
+    for case in gold["cases"]:
+        args = SimpleNamespace(query_type=case["query_type"])
+        ds = Stub(case["targets"])
+        # ---- one rank: the class itself, stage by stage
+        ref = case["by_world"]["1"][0]
+        m = RecallMetrics(ds, case["dense_run"], case["sparse_run"], case["fusion_run"], case["look_up"], case["qids"], args)
+        m.sort_and_count()
+        for name, counts in (("dense", m.dense_counts), ("sparse", m.sparse_counts), ("fusion", m.fusion_counts)):
+            assert {str(k): v for k, v in counts.items()} == ref["counts"][name], name
+        m.all_gather_object()
+        for name, lists in (("dense", m.dense_recall_lists), ("sparse", m.sparse_recall_lists), ("fusion", m.fusion_recall_lists)):
+            assert {str(k): v for k, v in lists.items()} == ref["lists"][name], name
+        buf = io.StringIO()
+        with contextlib.redirect_stdout(buf):
+            m.print_recall()
+        assert buf.getvalue() == ref["printed"]
+        # ---- two ranks: the sampler's split (with its padded repeat) and the reference's denominator, replayed
+        two = case["by_world"]["2"]
+        for r in (0, 1):
+            assert shard_query_ids(case["qids"], 2, r) == two[r]["shard"]
+        m2 = replay_ranks(ds, case["dense_run"], case["sparse_run"], case["fusion_run"], case["look_up"], case["qids"], args,
+                          world_size=2, compat=True)
+        for name, lists in (("dense", m2.dense_recall_lists), ("sparse", m2.sparse_recall_lists), ("fusion", m2.fusion_recall_lists)):
+            assert {str(k): v for k, v in lists.items()} == two[0]["lists"][name], name
+        buf = io.StringIO()
+        with contextlib.redirect_stdout(buf):
+            m2.print_recall()
+        assert buf.getvalue() == two[0]["printed"]
