@@ -1309,7 +1309,8 @@ static int hybrid_search_fused(msr_index* ix, msr_dense* dx, const int64_t* q_pt
     // queries per chunk: whole rounds of the chip's 256 CUs worth of 256 x 256 GEMM blocks, score rows <= ~160 MB so
     // that hybrid_tiles finds its row in the Infinity Cache (the row load is a dependent fetch at the start of the
     // epilogue: from HBM the same kernel measured 1.66 ms instead of 1.30 ms per 25 010 queries)
-    uint64_t row_blocks = std::max<uint64_t>(1, (160ull << 20) / (ld * 4 * 256));
+    static const uint64_t chunk_mb = getenv("MSR_HYBRID_CHUNK_MB") ? strtoull(getenv("MSR_HYBRID_CHUNK_MB"), nullptr, 0) : 160ull;  // diagnostic
+    uint64_t row_blocks = std::max<uint64_t>(1, (std::max<uint64_t>(chunk_mb, 1) << 20) / (ld * 4 * 256));
     if (col_blocks && row_blocks * col_blocks >= 256) row_blocks = row_blocks * col_blocks / 256 * 256 / col_blocks;
     const uint32_t qc = (uint32_t)std::min<uint64_t>(row_blocks * 256, std::max<uint32_t>(nq_pad, 256u));
     _Float16* d_Q = nullptr;
