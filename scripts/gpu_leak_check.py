@@ -1,5 +1,5 @@
-"""Handle / device-memory leak check: open, search, hybrid-search and close many times; the VRAM in use (rocm-smi) after
-the loop must be back at its value before it. usage: python scripts/gpu_leak_check.py [iterations]"""
+"""Handle / memory leak check: open, search, hybrid-search and close many times; the VRAM in use (rocm-smi) and the
+process's resident host memory after the loop must be back at their values before it. usage: python scripts/gpu_leak_check.py [iterations]"""
 import os
 import re
 import subprocess
@@ -44,14 +44,20 @@ def main():
             # (b is left to the index: closing the index detaches live batches)
     for _ in range(20):  # warm rounds: the runtime's own pools and code objects reach their steady size
         round_()
+    import psutil
+
+    proc = psutil.Process()
     base = vram_used()
+    rss0 = proc.memory_info().rss
     for i in range(iters):
         round_()
         if (i + 1) % 50 == 0:
             print(f"after {i + 1} rounds: VRAM used {vram_used() - base:+d} B vs after the warm rounds", flush=True)
     end = vram_used()
-    print(f"VRAM used: {base} B after 20 warm rounds, {end} B after {iters} more rounds ({end - base:+d} B)")
-    sys.exit(0 if base < 0 or end - base < (16 << 20) else 1)
+    rss1 = proc.memory_info().rss
+    print(f"VRAM used: {base} B after 20 warm rounds, {end} B after {iters} more rounds ({end - base:+d} B); "
+          f"host RSS {rss0 >> 20} -> {rss1 >> 20} MiB")
+    sys.exit(0 if (base < 0 or end - base < (16 << 20)) and rss1 - rss0 < (64 << 20) else 1)
 
 
 if __name__ == "__main__":
