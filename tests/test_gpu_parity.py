@@ -245,6 +245,35 @@ def test_resident_batch_and_shards(m, tmp_path):
         helpers.assert_same_results((o, sf, su, n), want, 10)
 
 
+def test_two_threads_two_handles(m, tmp_path):
+    # handles are not thread-safe, but two threads with a handle EACH may search at the same time (ctypes releases the
+    # GIL during the calls: the two streams, staging buffers and error strings must not meet)
+    import threading
+
+    docs, (qp, qt, qw) = helpers.synth(20000, 48, 400, 30, 3000, seed=61)
+    path = m.build_index_from_csr(str(tmp_path / "t.idx"), *docs, 3000, tile_docs=4096)
+    oix, _ = helpers.taat_oracle(docs, 3000)
+    want = {k: oix.search(qp, qt, qw, k, threads=8) for k in (10, 100)}
+    errors = []
+
+    def work(k):
+        try:
+            with m.SparseIndex(path, device=0) as ix:
+                for _ in range(20):
+                    helpers.assert_same_results(ix.search_csr(qp, qt, qw, k), want[k], k)
+                with pytest.raises(Exception, match="outside the dictionary"):   # an error in one thread stays there
+                    ix.search_csr(np.array([0, 1]), np.array([3000]), np.array([1]), k)
+        except BaseException as e:  # noqa: BLE001 (reported by the main thread)
+            errors.append(e)
+
+    ts = [threading.Thread(target=work, args=(k,)) for k in (10, 100, 10, 100)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not errors, errors
+
+
 def test_rccl_single_rank(m, tmp_path):
     # the RCCL exchange path with a 1-rank communicator (all a 1-GPU box can run)
     docs, (qp, qt, qw) = helpers.synth(12000, 32, 100, 30, 3000, seed=41)
