@@ -92,6 +92,20 @@ def c4_1m(n_docs=1_000_000, n_queries=10_000, n_terms=30000, seed=3, threads=16)
                     "text", f"synthetic {n_docs} docs x128 nnz, {n_queries} queries x120 nnz, V={n_terms}, top-10")
 
 
+def hybrid_vectors(n_docs, n_queries, h=4096, n_terms=30000, seed=4, threads=16):
+    """BASELINE config 5 and the reference's own hybrid run (scripts/search.sh:16-33): docs and queries with a sparse
+    (128 / 120 nnz) and a dense (h-d, unit norm: src/encode.py:301, src/search.py:342) vector each.
+    -> (doc CSR, query CSR, passage matrix f32 [n_docs, h], query matrix f32 [n_queries, h])"""
+    docs = synth_vectors(n_docs, 128, n_terms, seed=seed, threads=threads)
+    qp, qt, qw = synth_vectors(n_queries, 120, n_terms, seed=seed + 1, threads=threads)
+    rng = np.random.default_rng(seed)
+    p = rng.standard_normal((n_docs, h), dtype=np.float32)
+    p /= np.linalg.norm(p, axis=1, keepdims=True)
+    q = rng.standard_normal((n_queries, h), dtype=np.float32)
+    q /= np.linalg.norm(q, axis=1, keepdims=True)
+    return docs, (qp.astype(np.int64), qt.astype(np.int32), qw.astype(np.int32)), p, q
+
+
 def recall_at(ords, n, docids_of_ord, qrels, query_ids, query_type, ks=(1, 5, 10)):
     """Recall@k over result arrays (any-target-in-top-k, src/metrices.py:76-84) without building run dicts."""
     hits = {k: 0 for k in ks}
