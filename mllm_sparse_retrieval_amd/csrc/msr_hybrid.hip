@@ -4,6 +4,7 @@
 // for multi-tile indexes (fuse_tiles), the log1p-relu top-k sparsifier (sparsify_keys), and their C-ABI entry points.
 // Selection and list merging reuse the search path's kernels (launch_select / launch_merge, msr_device.hip).
 #include <chrono>
+#include <cmath>
 
 #include "msr_accumulate.hpp"
 #include "msr_gemm_w4.hpp"
@@ -382,13 +383,15 @@ struct msr_dense {
     bool lds_attr_set = false;  // dense_scores_256 needs the 128 KiB dynamic-LDS opt-in once per device
     // device scratch of the fused hybrid call (query matrix, score rows, result lists), kept between calls and only ever
     // grown: six hipMalloc / hipFree pairs of up to 200 MB cost a call more than its kernels
-    void* scratch[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-    size_t scratch_bytes[6] = {0, 0, 0, 0, 0, 0};
+    void* scratch[12] = {};
+    size_t scratch_bytes[12] = {};
+    uint64_t n_device_allocs = 0;  // hipMalloc calls made on behalf of this handle (steady-state calls make none)
     void* take(int slot, size_t bytes) {
         if (scratch_bytes[slot] >= bytes && scratch[slot]) return scratch[slot];
         if (scratch[slot]) (void)hipFree(scratch[slot]);
         scratch[slot] = nullptr;
         scratch_bytes[slot] = 0;
+        ++n_device_allocs;
         if (hipMalloc(&scratch[slot], bytes) != hipSuccess) {
             scratch[slot] = nullptr;
             return nullptr;
@@ -771,6 +774,17 @@ struct HybridArgs {
     uint32_t* out_ord;        // [nq][k]
     float* out_score;         // [nq][k] fused scores
     int32_t* out_n;           // [nq]
+    // ---- multi-tile indexes (MODE 1 of hybrid_tiles + hybrid_fuse_query): per (launch row, tile) candidate lists
+    const uint32_t* qlist;    // launch row -> query of the batch (second round: the flagged queries), or null: q0 + row
+    uint64_t* cand_s;         // [rows][n_tiles][stride] sparse candidates  score << 32 | ~ordinal  (0 = empty slot)
+    uint64_t* cand_d;         // [rows][n_tiles][stride] dense candidates   f32 key << 32 | ~ordinal
+    uint4* tile_meta;         // [rows][n_tiles][2]: {weakest emitted sparse composite (lo, hi), present sparse scores, all
+                              //   emitted?}, {weakest emitted dense composite (lo, hi), docs of the tile, all emitted?}
+    uint32_t n_tiles;         // tiles of the index
+    uint32_t stride;          // candidate slots per (row, tile, side)
+    uint32_t quota_full;      // candidates a full tile emits per side, <= stride
+    uint32_t quota_last;      // ... and the (shorter) last tile
+    uint32_t* flags;          // [nq] hybrid_fuse_query: 1 = the candidate lists did not cover a depth list (second round)
 };
 
 // The rare paths of hybrid_tiles, kept OUT OF LINE: inlined, the general selections' live ranges cost the common path
@@ -816,7 +830,13 @@ struct DualScratch {
     uint32_t fbin, fabove, fcnt, fn;  // final top-k: bin of the k-th best fused score, members above it, in it, collected
 };
 
-template <int TILE_DOCS, int NT, int U, int MIN_WAVES, bool DBG = false>
+// MODE 0: the fused single-tile kernel described above, grid = (queries).
+// MODE 1: multi-tile indexes, grid = (launch rows, tiles) like score_tiles: steps 1-3 for ONE tile with the tile's
+//   candidate QUOTA in the place of the depth, then every element at or above the two quota thresholds is written to the
+//   (row, tile) candidate lists; hybrid_fuse_query (below) finishes the query. Exact by verification: the quota is the
+//   tile's expected share of a depth list plus five standard deviations; a query whose depth-th best lies below some
+//   tile's weakest candidate is flagged and repeated with quota = depth (every tile's own top-depth: always enough).
+template <int TILE_DOCS, int NT, int U, int MIN_WAVES, bool DBG = false, int MODE = 0>
 __global__ __launch_bounds__(NT, MIN_WAVES) void hybrid_tiles(const ScoreArgs a, const HybridArgs h) {
     constexpr int CAND = 1024;
     constexpr int E = TILE_DOCS / NT, R = E / 4, NW = NT / 64, HW = NW / 2;
@@ -850,21 +870,23 @@ __global__ __launch_bounds__(NT, MIN_WAVES) void hybrid_tiles(const ScoreArgs a,
         }
     };
     stamp(-1);
-    const uint32_t q = a.q0 + blockIdx.x;
-    const uint32_t ndocs = (uint32_t)a.n_docs;  // single tile
+    const uint32_t q = (MODE == 1 && h.qlist) ? h.qlist[blockIdx.x] : a.q0 + blockIdx.x;
+    const uint32_t tile_l = MODE == 1 ? blockIdx.y : 0u;  // (the hybrid paths take whole indexes: local tile = global tile)
+    const uint64_t doc0 = (uint64_t)tile_l * TILE_DOCS;
+    const uint32_t ndocs = MODE == 1 ? (uint32_t)min((uint64_t)TILE_DOCS, a.n_docs - doc0) : (uint32_t)a.n_docs;
     const int rounds = (int)((ndocs + 4 * NT - 1) / (4 * NT));
     uint4* const a4 = reinterpret_cast<uint4*>(acc);
     if (tid < 8) ds.red[tid] = 0;  // (ordered before their first use by accumulate_tile's barriers)
     if (tid < 2) ds.ncand[tid] = 0;
     if (tid == 0) ds.fn = 0;
-    accumulate_tile<TILE_DOCS, NT, U, false>(a, q, 0u, rounds, lds, ss, [](int) {}, tid);
+    accumulate_tile<TILE_DOCS, NT, U, false>(a, q, tile_l, rounds, lds, ss, [](int) {}, tid);
     stamp(0);
 
     // ---- the query's row of dense scores (the GEMM wrote the f32 values in ORDINAL order) in registers; docs past the
     // corpus become NaN: min / max skip them, every comparison with them is false
     float df[E];
     {
-        const uint4* row = reinterpret_cast<const uint4*>(h.dkeys + (uint64_t)blockIdx.x * h.ld);
+        const uint4* row = reinterpret_cast<const uint4*>(h.dkeys + (uint64_t)blockIdx.x * h.ld + doc0);
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             const uint4 x = r < rounds ? row[r * NT + tid] : make_uint4(0, 0, 0, 0);
@@ -915,8 +937,9 @@ __global__ __launch_bounds__(NT, MIN_WAVES) void hybrid_tiles(const ScoreArgs a,
     const uint32_t smin_u = n_s ? ~ds.red[1] + 1u : 0u;
     const uint32_t n_d = ndocs;  // every doc has a dense score
     const float dmax_f = key_to_f32(ds.red[3]), dmin_all = key_to_f32(~ds.red[4]);
-    // list sizes: the depth best, or everything that is present
-    const uint32_t need_s = min(h.depth, n_s), need_d = min(h.depth, n_d);
+    // list sizes: the depth best (MODE 1: the tile's quota of candidates), or everything that is present
+    const uint32_t want = MODE == 1 ? (tile_l + 1 == h.n_tiles ? h.quota_last : h.quota_full) : h.depth;
+    const uint32_t need_s = min(want, n_s), need_d = min(want, n_d);
     // ---- pass B: histograms, linear between the smallest and the largest present value of each side (an absent
     // sparse score, 0, saturates to bin 0, a doc past the corpus, NaN, converts to bin 0: harmless, the chosen bin's
     // candidates are filtered by presence). Branch-free: one fused multiply-add,
@@ -1053,11 +1076,61 @@ __global__ __launch_bounds__(NT, MIN_WAVES) void hybrid_tiles(const ScoreArgs a,
     uint64_t T_s = ds.T[0], T_d = ds.T[1];
     // ---- rare: a side without spread, or a bin with more than kHistCand elements (mass ties): the general selection
     if (__builtin_expect(n_s != 0 && !fast_s, 0))  // (uniform, rare)
-        T_s = threshold_general<TILE_DOCS, NT>(acc, rounds, ndocs, h.depth, false, hist, cand + kHistBins / 2, &hs, tid);
+        T_s = threshold_general<TILE_DOCS, NT>(acc, rounds, ndocs, want, false, hist, cand + kHistBins / 2, &hs, tid);
     if (__builtin_expect(!fast_d, 0))
-        T_d = threshold_general<TILE_DOCS, NT>(h.dkeys + (uint64_t)blockIdx.x * h.ld, rounds, ndocs, h.depth, true, hist,
+        T_d = threshold_general<TILE_DOCS, NT>(h.dkeys + (uint64_t)blockIdx.x * h.ld + doc0, rounds, ndocs, want, true, hist,
                                                cand + kHistBins / 2, &hs, tid);
     stamp(1);
+    if constexpr (MODE == 1) {
+        // ---- the tile's candidates: every element at or above its side's threshold composite (exactly need_s / need_d
+        // of them: composites are unique), as GLOBAL composites  score or f32 key << 32 | ~ordinal, in any order
+        __syncthreads();  // (everyone has read ds.ncand / ds.T of the selection)
+        if (tid < 2) ds.ncand[tid] = 0;
+        __syncthreads();
+        const uint64_t slot0 = ((uint64_t)blockIdx.x * h.n_tiles + tile_l) * h.stride;
+        uint64_t* const cs = h.cand_s + slot0;
+        uint64_t* const cd = h.cand_d + slot0;
+        const uint32_t ts_key = (uint32_t)(T_s >> 13), ts_inv = (uint32_t)T_s & 8191u;
+        const uint32_t td_inv = (uint32_t)T_d & 8191u;
+        const float td_f = key_to_f32((uint32_t)(T_d >> 13)) + 0.0f;
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+            if (r < rounds) {
+                const uint4 x = a4[r * NT + tid];
+                const uint32_t s4[4] = {x.x, x.y, x.z, x.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const uint32_t local = 4u * ((uint32_t)r * NT + tid) + (uint32_t)e;
+                    const uint32_t inv = (uint32_t)(TILE_DOCS - 1) - local;
+                    const uint32_t nord = 0xFFFFFFFFu - (uint32_t)(doc0 + local);
+                    const float d = df[4 * r + e];
+                    if (need_s && s4[e] != 0 && (s4[e] > ts_key || (s4[e] == ts_key && inv >= ts_inv))) {
+                        const uint32_t pos = atomicAdd(&ds.ncand[0], 1u);
+                        if (pos < h.stride) cs[pos] = ((uint64_t)s4[e] << 32) | nord;
+                    }
+                    if (d > td_f || (d == td_f && inv >= td_inv)) {  // (NaN = past the corpus: never)
+                        const uint32_t pos = atomicAdd(&ds.ncand[1], 1u);
+                        if (pos < h.stride) cd[pos] = ((uint64_t)f32_to_key(d) << 32) | nord;
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        __syncthreads();
+        const uint32_t got_s = min(ds.ncand[0], h.stride), got_d = min(ds.ncand[1], h.stride);
+        for (uint32_t i = got_s + tid; i < h.stride; i += NT) cs[i] = 0ull;  // empty slots
+        for (uint32_t i = got_d + tid; i < h.stride; i += NT) cd[i] = 0ull;
+        if (tid == 0) {
+            // weakest emitted element of each side as a global composite; "all emitted" = the list holds everything the
+            // tile has (no threshold to respect)
+            const uint32_t tl_s = (uint32_t)(TILE_DOCS - 1) - ts_inv, tl_d = (uint32_t)(TILE_DOCS - 1) - td_inv;
+            const uint64_t ws = ((uint64_t)ts_key << 32) | (0xFFFFFFFFu - (uint32_t)(doc0 + tl_s));
+            const uint64_t wd = ((uint64_t)(uint32_t)(T_d >> 13) << 32) | (0xFFFFFFFFu - (uint32_t)(doc0 + tl_d));
+            uint4* m = h.tile_meta + ((uint64_t)blockIdx.x * h.n_tiles + tile_l) * 2;
+            m[0] = make_uint4((uint32_t)ws, (uint32_t)(ws >> 32), n_s, need_s == n_s ? 1u : 0u);
+            m[1] = make_uint4((uint32_t)wd, (uint32_t)(wd >> 32), n_d, need_d == n_d ? 1u : 0u);
+        }
+        return;
+    }
     // ---- fusion (src/hybrid.py:32-53): min = the last member's score, max = the best, per side; fused keys go to the
     // accumulator tile (each thread rewrites only what it has read) and into a histogram over [fmin, fmax]
     const uint32_t ts_key = (uint32_t)(T_s >> 13), ts_inv = (uint32_t)T_s & 8191u;
@@ -1227,6 +1300,286 @@ __global__ __launch_bounds__(NT, MIN_WAVES) void hybrid_tiles(const ScoreArgs a,
     }
 }
 
+// ------------------------------------------------------------------------------------------------ multi-tile: per query
+// need-th largest of the workgroup's non-zero u64 keys (unique; 0 = empty slot; each(f) calls f(key) for every key of the
+// calling thread — registers, LDS or global memory, the caller's choice), by radix passes of 8 bits over the bits
+// BELOW the keys' common prefix (scores of one list differ in their low 20 bits or so: the pass that matters comes first;
+// a pass ends the search as soon as the chosen bin holds <= 64 keys, which are then ranked by one wave). Returns T with
+// "key belongs to the need best  <=>  key != 0 and key >= T";  *present = non-zero keys, *kmax = the largest.
+// need == 0: T = ~0 (nothing belongs); need >= present: T = the smallest key (everything belongs).
+struct KthScratch {
+    uint32_t hist[256];
+    uint64_t wmin[16], wmax[16];
+    uint32_t wcnt[16];
+    uint64_t small[64];
+    uint32_t n_small, pad;
+    uint64_t T;
+};
+
+template <int NT, class Each>
+__device__ __forceinline__ uint64_t kth_largest_u64(Each each, uint32_t need, KthScratch& ks, const uint32_t tid,
+                                                    uint32_t* present, uint64_t* kmax) {
+    constexpr int NW = NT / 64;
+    const uint32_t lane = tid & 63, wave = rfl(tid >> 6);
+    uint64_t mn = ~0ull, mx = 0;
+    uint32_t c = 0;
+    each([&](const uint64_t key) {
+        if (key) {
+            mn = key < mn ? key : mn;
+            mx = key > mx ? key : mx;
+            ++c;
+        }
+    });
+    mn = ~wave_max_u64(~mn);
+    mx = wave_max_u64(mx);
+    c = wave_sum_u32(c);
+    __syncthreads();  // previous users of the scratch are done
+    if (lane == 0) {
+        ks.wmin[wave] = mn;
+        ks.wmax[wave] = mx;
+        ks.wcnt[wave] = c;
+    }
+    if (tid == 0) ks.n_small = 0;
+    __syncthreads();
+    mn = ~0ull, mx = 0, c = 0;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) {
+        mn = ks.wmin[w] < mn ? ks.wmin[w] : mn;
+        mx = ks.wmax[w] > mx ? ks.wmax[w] : mx;
+        c += ks.wcnt[w];
+    }
+    *present = c;
+    *kmax = mx;
+    if (need == 0 || c == 0) return ~0ull;
+    if (need >= c) return mn;
+    // (two or more keys, all different: mx != mn)
+    const int top = 63 - __clzll((long long)(mx ^ mn));
+    int shift = max(top - 7, 0);
+    uint64_t hi_mask = shift + 8 >= 64 ? 0ull : ~0ull << (shift + 8);
+    uint64_t prefix = mx & hi_mask;
+#pragma unroll 1
+    for (;;) {
+        ks.hist[tid & 255u] = 0;  // (NT >= 256)
+        __syncthreads();
+        each([&](const uint64_t key) {
+            if (key && (key & hi_mask) == prefix) atomicAdd(&ks.hist[(uint32_t)(key >> shift) & 255u], 1u);
+        });
+        __syncthreads();
+        // every wave finds the bin of the need-th largest for itself: lane l owns bins 4l .. 4l+3
+        const uint4 hb = reinterpret_cast<const uint4*>(ks.hist)[lane];
+        const uint32_t sum4 = hb.x + hb.y + hb.z + hb.w;
+        const uint32_t inc = wave_inclusive_scan_u32(sum4);
+        const uint32_t suf = rdl(inc, 63) - (inc - sum4);  // keys in bins >= 4 * lane: non-increasing in lane
+        const uint32_t L = 63u - (uint32_t)__clzll((long long)__ballot(suf >= need));
+        uint32_t above = rdl(suf, L) - rdl(sum4, L);
+        const uint32_t b3 = rdl(hb.w, L), b2 = rdl(hb.z, L), b1 = rdl(hb.y, L), b0 = rdl(hb.x, L);
+        uint32_t bin = 4 * L + 3, cnt = b3;
+        if (above + b3 < need) {
+            above += b3, bin = 4 * L + 2, cnt = b2;
+            if (above + b2 < need) {
+                above += b2, bin = 4 * L + 1, cnt = b1;
+                if (above + b1 < need) above += b1, bin = 4 * L, cnt = b0;
+            }
+        }
+        need -= above;  // rank inside the chosen bin, 1-based from the top
+        prefix |= (uint64_t)bin << shift;
+        hi_mask |= 255ull << shift;
+        if (cnt <= 64 || shift == 0) {
+            each([&](const uint64_t key) {
+                if (key && (key & hi_mask) == prefix) ks.small[atomicAdd(&ks.n_small, 1u)] = key;
+            });
+            __syncthreads();
+            if (tid < 64) {
+                const uint64_t me = lane < cnt ? ks.small[lane] : 0ull;
+                const uint32_t lo = (uint32_t)me, hi = (uint32_t)(me >> 32);
+                uint32_t rank = 0;
+                for (uint32_t i = 0; i < cnt; ++i) {
+                    const uint64_t o = ((uint64_t)rdl(hi, i) << 32) | rdl(lo, i);
+                    rank += o > me;
+                }
+                if (lane < cnt && rank == need - 1) ks.T = me;
+            }
+            __syncthreads();
+            return ks.T;
+        }
+        shift = max(shift - 8, 0);  // (the last window may overlap bits that are already fixed: harmless)
+        __syncthreads();            // everyone has read the histogram
+    }
+}
+
+// Multi-tile indexes, second kernel: ONE workgroup per query finishes what hybrid_tiles<MODE 1> prepared — the depth-th
+// best of each side among the tiles' candidates (exact when every tile's weakest candidate lies at or below it: checked,
+// else the query is flagged for the second round), the reference's fusion over the union of the two lists
+// (src/hybrid.py:32-53: min = the depth-th score, max = the best, of the UNFILTERED lists, src/search.py:76-81; the
+// query's own doc skipped, src/search.py:72-74) in an LDS hash table keyed by doc ordinal, and the top-k of the fused
+// scores (ties: lower ordinal). k <= 1024, depth <= 1024.
+constexpr int kFuseSlots = 4096;  // >= 2 x the 2 x 1024 members a union can hold
+
+template <int NT>
+__global__ __launch_bounds__(NT) void hybrid_fuse_query(const HybridArgs h, const uint32_t q0) {
+    static_assert(NT >= 256 && NT % 64 == 0 && NT / 64 <= 16, "scratch layout");
+    __shared__ uint32_t hkey[kFuseSlots];   // doc ordinal + 1 (0 = free)
+    __shared__ float hval[kFuseSlots];      // fused score
+    __shared__ __attribute__((aligned(16))) uint64_t cand[kCandCap];
+    __shared__ __attribute__((aligned(16))) KthScratch ks;
+    __shared__ uint32_t red[4];             // present sparse scores, docs, invalid flag, members
+    const uint32_t tid = threadIdx.x, lane = tid & 63;
+    const uint32_t row = blockIdx.x;
+    const uint32_t q = h.qlist ? h.qlist[row] : q0 + row;
+    const uint32_t n_slots = h.n_tiles * h.stride;
+    const uint64_t* const cs = h.cand_s + (uint64_t)row * n_slots;
+    const uint64_t* const cd = h.cand_d + (uint64_t)row * n_slots;
+    const uint4* const meta = h.tile_meta + (uint64_t)row * h.n_tiles * 2;
+    if (tid < 4) red[tid] = 0;
+    for (uint32_t i = tid; i < kFuseSlots; i += NT) hkey[i] = 0;
+    __syncthreads();
+    {
+        uint32_t ns = 0, nd = 0;
+        for (uint32_t t = tid; t < h.n_tiles; t += NT) {
+            ns += meta[2 * t].z;
+            nd += meta[2 * t + 1].z;
+        }
+        ns = wave_sum_u32(ns);
+        nd = wave_sum_u32(nd);
+        if (lane == 0 && (ns | nd)) {
+            atomicAdd(&red[0], ns);
+            atomicAdd(&red[1], nd);
+        }
+    }
+    __syncthreads();
+    const uint32_t need_s = min(h.depth, red[0]), need_d = min(h.depth, red[1]);
+    // The query's candidates live in REGISTERS when they fit (EPT per thread and side: 4 tiles x 418 of the reference's
+    // own shape are 1 672 per side): all loads are issued back to back, once. Read in a loop from global memory, every
+    // pass below pays a dependent L2 round trip per element (measured: 0.47 ms instead of 0.2 for 5 000 queries).
+    constexpr int EPT = 8;
+    const bool in_regs = n_slots <= (uint32_t)(EPT * NT);  // (uniform)
+    uint64_t rs[EPT], rd[EPT];
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) {
+        const uint32_t i = tid + (uint32_t)e * NT;
+        const bool live = in_regs && i < n_slots;
+        rs[e] = live ? cs[i] : 0ull;
+        rd[e] = live ? cd[i] : 0ull;
+    }
+    auto each_s = [&](auto f) {
+        if (in_regs) {
+#pragma unroll
+            for (int e = 0; e < EPT; ++e) f(rs[e]);
+        } else {
+            for (uint32_t i = tid; i < n_slots; i += NT) f(cs[i]);
+        }
+    };
+    auto each_d = [&](auto f) {
+        if (in_regs) {
+#pragma unroll
+            for (int e = 0; e < EPT; ++e) f(rd[e]);
+        } else {
+            for (uint32_t i = tid; i < n_slots; i += NT) f(cd[i]);
+        }
+    };
+    uint32_t c_s, c_d;
+    uint64_t mx_s, mx_d;
+    const uint64_t T_s = kth_largest_u64<NT>(each_s, need_s, ks, tid, &c_s, &mx_s);
+    const uint64_t T_d = kth_largest_u64<NT>(each_d, need_d, ks, tid, &c_d, &mx_d);
+    // ---- are the lists complete? a tile that did not emit everything it has must have its weakest candidate at or
+    // below the side's depth-th best
+    {
+        bool bad = c_s < need_s || c_d < need_d;
+        for (uint32_t t = tid; t < h.n_tiles; t += NT) {
+            const uint4 a = meta[2 * t], b = meta[2 * t + 1];
+            if (need_s && !a.w && T_s < (((uint64_t)a.y << 32) | a.x)) bad = true;
+            if (need_d && !b.w && T_d < (((uint64_t)b.y << 32) | b.x)) bad = true;
+        }
+        if (bad) red[2] = 1;  // (benign race: every writer stores 1)
+    }
+    __syncthreads();
+    if (red[2]) {  // (uniform) second round: hybrid_tiles<MODE 1> with quota = depth for this query
+        if (tid == 0) {
+            h.flags[q] = 1;
+            h.out_n[q] = 0;
+        }
+        return;
+    }
+    // ---- fusion: dense members first (the reference adds the dense term first: runs = [dense, sparse], src/search.py:459)
+    const uint32_t self = h.self_ord ? (uint32_t)h.self_ord[q] : 0xFFFFFFFFu;
+    const uint32_t smax_u = (uint32_t)(mx_s >> 32), smin_u = need_s ? (uint32_t)(T_s >> 32) : 0u;
+    const float smax = need_s ? (float)smax_u : 0.f, smin = (float)smin_u;
+    const float dmax = need_d ? key_to_f32((uint32_t)(mx_d >> 32)) + 0.0f : 0.f;
+    const float dmin = need_d ? key_to_f32((uint32_t)(T_d >> 32)) + 0.0f : 0.f;
+    const float inv_sden = 1.0f / fmaxf(smax - smin, 1e-9f), inv_dden = 1.0f / fmaxf(dmax - dmin, 1e-9f);
+    const bool spread_s = smax > smin, spread_d = dmax > dmin;
+    auto slot_of = [](uint32_t ord) { return (ord * 2654435761u) >> 20; };  // 12 bits
+    if (need_d)
+        each_d([&](const uint64_t key) {
+            if (!key || key < T_d) return;
+            const uint32_t ord = 0xFFFFFFFFu - (uint32_t)key;
+            if (ord == self) return;
+            const float d = key_to_f32((uint32_t)(key >> 32)) + 0.0f;
+            // (EXACTLY 1 at the maximum, as the reference's quotient is: see hybrid_tiles)
+            const float v = 0.f + h.w_dense * ((d == dmax && spread_d) ? 1.0f : (d - dmin) * inv_dden);
+            uint32_t sl = slot_of(ord);
+            while (atomicCAS(&hkey[sl], 0u, ord + 1u) != 0u) sl = (sl + 1u) & (kFuseSlots - 1);  // (dense docs are unique)
+            hval[sl] = v;
+        });
+    __syncthreads();
+    if (need_s)
+        each_s([&](const uint64_t key) {
+            if (!key || key < T_s) return;
+            const uint32_t ord = 0xFFFFFFFFu - (uint32_t)key;
+            if (ord == self) return;
+            const uint32_t sc = (uint32_t)(key >> 32);
+            const float v = h.w_sparse * ((sc == smax_u && spread_s) ? 1.0f : ((float)sc - smin) * inv_sden);
+            uint32_t sl = slot_of(ord);
+            for (;;) {
+                const uint32_t old = atomicCAS(&hkey[sl], 0u, ord + 1u);
+                if (old == 0u) {          // not in the dense list: a fresh entry (sparse docs are unique: no other writer)
+                    hval[sl] = 0.f + v;
+                    break;
+                }
+                if (old == ord + 1u) {    // in the dense list as well (inserted before the barrier): add the sparse term
+                    hval[sl] += v;
+                    break;
+                }
+                sl = (sl + 1u) & (kFuseSlots - 1);
+            }
+        });
+    __syncthreads();
+    // ---- top-k of the fused scores over the union (ties: lower ordinal)
+    auto fused_key = [&](uint32_t i) -> uint64_t {
+        const uint32_t kk = hkey[i];
+        return kk ? ((uint64_t)f32_to_key(hval[i]) << 32) | (uint64_t)(0xFFFFFFFFu - (kk - 1u)) : 0ull;
+    };
+    uint32_t members;
+    uint64_t mx_f;
+    auto each_f = [&](auto f) {
+        for (uint32_t i = tid; i < (uint32_t)kFuseSlots; i += NT) f(fused_key(i));
+    };
+    const uint64_t T_f = kth_largest_u64<NT>(each_f, h.k, ks, tid, &members, &mx_f);
+    const uint32_t n_out = min(h.k, members);
+    for (uint32_t i = tid; i < (uint32_t)kFuseSlots; i += NT) {
+        const uint64_t key = fused_key(i);
+        if (key && key >= T_f) {
+            const uint32_t pos = atomicAdd(&red[3], 1u);
+            if (pos < (uint32_t)kCandCap) cand[pos] = key;
+        }
+    }
+    __syncthreads();
+    uint64_t* const res = reinterpret_cast<uint64_t*>(hkey);  // (the table is dead: 4096 x 4 B = 2048 keys >= k)
+    __syncthreads();
+    rank_and_emit<NT, true>(cand, (int)n_out, (int)h.k, res, tid);
+    __syncthreads();
+    for (uint32_t i = tid; i < h.k; i += NT) {
+        const uint64_t key = res[i];
+        const uint64_t o = (uint64_t)q * h.k + i;
+        h.out_ord[o] = key ? 0xFFFFFFFFu - (uint32_t)key : 0xFFFFFFFFu;
+        h.out_score[o] = key ? key_to_f32((uint32_t)(key >> 32)) : 0.f;
+    }
+    if (tid == 0) {
+        h.out_n[q] = (int32_t)n_out;
+        h.flags[q] = 0;
+    }
+}
+
 // rows of the passage matrix in ORDINAL order: P_ord[row2ord[r]] = P[r]
 __global__ __launch_bounds__(256) void permute_rows(const uint4* __restrict__ src, uint4* __restrict__ dst,
                                                     const uint32_t* __restrict__ row2ord, uint32_t vecs_per_row) {
@@ -1237,6 +1590,45 @@ __global__ __launch_bounds__(256) void permute_rows(const uint4* __restrict__ sr
 }
 
 }  // namespace msr
+
+// Passage rows in doc-ORDINAL order (P_ord[row2ord[r]] = P[r]), so that a query's row of GEMM output lines up with the
+// sparse accumulator tiles; built on first use, cached on the dense handle while the mapping is unchanged.
+static int ensure_ordinal_rows(msr_dense* dx, hipStream_t stream, const uint32_t* row2ord, const uint64_t n) {
+    if (!dx->d_P_ord || dx->ord_map.size() != n || memcmp(dx->ord_map.data(), row2ord, (size_t)n * 4) != 0) {
+        std::vector<uint8_t> seen((size_t)n, 0);
+        for (uint64_t r = 0; r < n; ++r) {
+            if (row2ord[r] >= n || seen[row2ord[r]]) {
+                set_error("row2ord is not a permutation of the doc ordinals (row %llu -> %u)", (unsigned long long)r, row2ord[r]);
+                return MSR_E_INVAL;
+            }
+            seen[row2ord[r]] = 1;
+        }
+        uint32_t* d_map = nullptr;
+        const size_t bytes = (size_t)dx->n_pad * dx->h * 2;
+        if (!dx->d_P_ord && hipMalloc(&dx->d_P_ord, bytes) != hipSuccess) {
+            dx->d_P_ord = nullptr;
+            set_error("hipMalloc of %zu bytes for the ordinal-ordered passage matrix failed", bytes);
+            return MSR_E_NOMEM;
+        }
+        bool ok = hipMalloc(&d_map, std::max<size_t>((size_t)n, 1) * 4) == hipSuccess &&
+                  hipMemsetAsync(dx->d_P_ord, 0, bytes, stream) == hipSuccess &&
+                  hipMemcpyAsync(d_map, row2ord, (size_t)n * 4, hipMemcpyHostToDevice, stream) == hipSuccess;
+        if (ok && n) {
+            hipLaunchKernelGGL(permute_rows, dim3((uint32_t)n), dim3(256), 0, stream, reinterpret_cast<const uint4*>(dx->d_P),
+                               reinterpret_cast<uint4*>(dx->d_P_ord), d_map, dx->h / 8);
+            ok = hipGetLastError() == hipSuccess;
+        }
+        ok = ok && hipStreamSynchronize(stream) == hipSuccess;
+        if (d_map) (void)hipFree(d_map);
+        if (!ok) {
+            dx->ord_map.clear();
+            set_error("building the ordinal-ordered passage matrix failed: %s", hipGetErrorString(hipGetLastError()));
+            return MSR_E_HIP;
+        }
+        dx->ord_map.assign(row2ord, row2ord + n);
+    }
+    return MSR_OK;
+}
 
 // The fused path of msr_hybrid_search (single-tile indexes, k <= 64): per chunk of queries (normally ONE chunk) a GEMM
 // launch on the ordinal-permuted passage matrix, then hybrid_tiles. ms = {fused scoring + selection + fusion kernel, dense GEMM, 0, 0}.
@@ -1261,40 +1653,7 @@ static int hybrid_search_fused(msr_index* ix, msr_dense* dx, const int64_t* q_pt
         t_last = now;
         if (laps_n < sizeof(laps)) laps_n += (size_t)snprintf(laps + laps_n, sizeof(laps) - laps_n, " %s %.2f", what, msx);
     };
-    // ---- passage rows in ordinal order (cached on the dense handle while the mapping is unchanged)
-    if (!dx->d_P_ord || dx->ord_map.size() != n || memcmp(dx->ord_map.data(), row2ord, (size_t)n * 4) != 0) {
-        std::vector<uint8_t> seen((size_t)n, 0);
-        for (uint64_t r = 0; r < n; ++r) {
-            if (row2ord[r] >= n || seen[row2ord[r]]) {
-                set_error("row2ord is not a permutation of the doc ordinals (row %llu -> %u)", (unsigned long long)r, row2ord[r]);
-                return MSR_E_INVAL;
-            }
-            seen[row2ord[r]] = 1;
-        }
-        uint32_t* d_map = nullptr;
-        const size_t bytes = (size_t)dx->n_pad * dx->h * 2;
-        if (!dx->d_P_ord && hipMalloc(&dx->d_P_ord, bytes) != hipSuccess) {
-            dx->d_P_ord = nullptr;
-            set_error("hipMalloc of %zu bytes for the ordinal-ordered passage matrix failed", bytes);
-            return MSR_E_NOMEM;
-        }
-        bool ok = hipMalloc(&d_map, std::max<size_t>((size_t)n, 1) * 4) == hipSuccess &&
-                  hipMemsetAsync(dx->d_P_ord, 0, bytes, d->stream) == hipSuccess &&
-                  hipMemcpyAsync(d_map, row2ord, (size_t)n * 4, hipMemcpyHostToDevice, d->stream) == hipSuccess;
-        if (ok && n) {
-            hipLaunchKernelGGL(permute_rows, dim3((uint32_t)n), dim3(256), 0, d->stream, reinterpret_cast<const uint4*>(dx->d_P),
-                               reinterpret_cast<uint4*>(dx->d_P_ord), d_map, dx->h / 8);
-            ok = hipGetLastError() == hipSuccess;
-        }
-        ok = ok && hipStreamSynchronize(d->stream) == hipSuccess;
-        if (d_map) (void)hipFree(d_map);
-        if (!ok) {
-            dx->ord_map.clear();
-            set_error("building the ordinal-ordered passage matrix failed: %s", hipGetErrorString(hipGetLastError()));
-            return MSR_E_HIP;
-        }
-        dx->ord_map.assign(row2ord, row2ord + n);
-    }
+    if (int rc0 = ensure_ordinal_rows(dx, d->stream, row2ord, n)) return rc0;
     lap("ordinal map");
     msr_batch* b = nullptr;
     int rc = msr_batch_create(ix, q_ptr, q_term, q_w, nq, k, flags, &b);
@@ -1468,6 +1827,275 @@ static int hybrid_search_fused(msr_index* ix, msr_dense* dx, const int64_t* q_pt
     return rc;
 }
 
+// Candidate quota of a tile that holds `tile_docs` of the corpus's `n` docs: its expected share of a depth list plus
+// five standard deviations (docs are numbered by id string, so a tile's share of any query's best docs is a draw without
+// replacement) plus a constant; never more than the depth. A query for which some tile needed more is repeated with
+// quota = depth by the caller, so the result never depends on this number.
+static uint32_t tile_quota(uint64_t tile_docs, uint64_t n, uint32_t depth) {
+    const char* env = getenv("MSR_HYBRID_QUOTA");  // diagnostic / tests (read per call: a test flips it)
+    const long forced = env ? atol(env) : 0;
+    if (forced > 0) return (uint32_t)std::min<long>(forced, depth);
+    if (n == 0 || tile_docs >= n) return depth;
+    const double share = (double)tile_docs / (double)n, mean = depth * share;
+    const double q = mean + 5.0 * std::sqrt(mean * (1.0 - share)) + 16.0;
+    return (uint32_t)std::min<double>(depth, std::ceil(q));
+}
+
+// Multi-tile indexes (and k > 64 on one tile): per chunk of queries a GEMM launch on the ordinal-permuted passage matrix,
+// hybrid_tiles<MODE 1> over (query, tile) and hybrid_fuse_query over the queries; flagged queries (normally none) are
+// repeated with quota = depth. ms = {candidate kernel, dense GEMM, 0, fusion kernel}.
+static int hybrid_search_multitile(msr_index* ix, msr_dense* dx, const int64_t* q_ptr, const int32_t* q_term,
+                                   const int32_t* q_w, const uint16_t* q_fp16, int nq, int depth, int k, float alpha,
+                                   uint32_t flags, const uint32_t* row2ord, const int32_t* self_ord, uint32_t* out_ord,
+                                   float* out_score, int32_t* out_n, float ms[4]) {
+    DeviceIndex* d = ix->dev;
+    const IndexHeader* h = ix->host.h;
+    const uint64_t n = h->n_docs;
+    const uint32_t tile = h->tile_docs, n_tiles = h->n_tiles;
+    HIP_TRY(hipSetDevice(d->device));
+    if (int rc0 = ensure_ordinal_rows(dx, d->stream, row2ord, n)) return rc0;
+    msr_batch* b = nullptr;
+    int rc = msr_batch_create(ix, q_ptr, q_term, q_w, nq, 1, flags, &b);  // (only the query arrays are used)
+    if (rc != MSR_OK) return rc;
+    const uint64_t ld = (uint64_t)n_tiles * tile;  // a query's score row: tile t starts at column t * tile
+    const uint64_t n_cover = std::min<uint64_t>(dx->n_pad, (n + 255) / 256 * 256);
+    const uint32_t col_blocks = (uint32_t)(n_cover / 256);
+    const uint32_t nq_pad = (uint32_t)((nq + 255) / 256 * 256);
+    // queries per chunk: score rows of ~160 MB (they are read back out of the Infinity Cache), whole rounds of the
+    // chip's 256 CUs worth of GEMM blocks
+    static const uint64_t chunk_mb = getenv("MSR_HYBRID_CHUNK_MB") ? strtoull(getenv("MSR_HYBRID_CHUNK_MB"), nullptr, 0) : 160ull;
+    // (the bytes that travel are the n_cover written columns of a row, not its padded stride). Among the chunk sizes
+    // that fit, the one whose GEMM grid fills its last round of 256 CUs best: 2 x 98 blocks leave a quarter of the chip
+    // idle, 5 x 98 = 490 fill 1.91 rounds
+    const uint64_t rb_max = std::max<uint64_t>(1, (std::max<uint64_t>(chunk_mb, 1) << 20) / (std::max<uint64_t>(n_cover, 256) * 4 * 256));
+    uint64_t row_blocks = 1;
+    double best_eff = 0;
+    for (uint64_t rb = 1; rb <= std::min<uint64_t>(rb_max, nq_pad / 256); ++rb) {
+        const uint64_t blocks = rb * std::max<uint32_t>(col_blocks, 1);
+        const double eff = (double)blocks / (double)((blocks + 255) / 256 * 256);
+        if (eff >= best_eff - 1e-9) best_eff = eff, row_blocks = rb;
+    }
+    const uint32_t qc = (uint32_t)std::min<uint64_t>(row_blocks * 256, std::max<uint32_t>(nq_pad, 256u));
+    const uint64_t last_docs = n - (uint64_t)(n_tiles - 1) * tile;
+    const uint32_t quota_full = n_tiles > 1 ? tile_quota(tile, n, (uint32_t)depth) : tile_quota(n, n, (uint32_t)depth);
+    const uint32_t quota_last = n_tiles > 1 ? std::min(quota_full, tile_quota(last_docs, n, (uint32_t)depth)) : quota_full;
+    // candidate slots: a chunk of the first round (qc rows x quota_full) or at least ONE row of the second (depth)
+    const size_t per_tile_row = (size_t)n_tiles;
+    const size_t cand_slots = std::max<size_t>((size_t)qc * per_tile_row * quota_full, per_tile_row * (size_t)depth);
+    const size_t perk = std::max<size_t>((size_t)nq * k, 1);
+    _Float16* d_Q = (_Float16*)dx->take(0, std::max<size_t>((size_t)nq_pad * dx->h * 2, 16));
+    uint32_t* d_S = (uint32_t*)dx->take(1, (size_t)qc * ld * 4);
+    uint32_t* d_ord = (uint32_t*)dx->take(2, perk * 4);
+    float* d_sf = (float*)dx->take(3, perk * 4);
+    int32_t* d_n = (int32_t*)dx->take(4, std::max<size_t>(nq, 1) * 4);
+    uint64_t* d_cs = (uint64_t*)dx->take(6, cand_slots * 8);
+    uint64_t* d_cd = (uint64_t*)dx->take(7, cand_slots * 8);
+    uint4* d_meta = (uint4*)dx->take(8, std::max<size_t>((size_t)qc * per_tile_row * 2 * 16, 32));
+    uint32_t* d_flags = (uint32_t*)dx->take(9, std::max<size_t>(nq, 1) * 4);
+    uint32_t* d_qlist = (uint32_t*)dx->take(10, std::max<size_t>(nq, 1) * 4);
+    int32_t* d_self = nullptr;
+    bool ok = d_Q && d_S && d_ord && d_sf && d_n && d_cs && d_cd && d_meta && d_flags && d_qlist;
+    if (ok && self_ord)
+        ok = (d_self = (int32_t*)dx->take(5, std::max<size_t>(nq, 1) * 4)) != nullptr &&
+             hipMemcpyAsync(d_self, self_ord, (size_t)nq * 4, hipMemcpyHostToDevice, d->stream) == hipSuccess;
+    if (ok && nq)
+        ok = hipMemsetAsync(d_Q + (size_t)nq * dx->h, 0, (size_t)(nq_pad - nq) * dx->h * 2, d->stream) == hipSuccess &&
+             hipMemcpyAsync(d_Q, q_fp16, (size_t)nq * dx->h * 2, hipMemcpyHostToDevice, d->stream) == hipSuccess;
+    if (!ok) {
+        set_error("device allocation or query upload failed in msr_hybrid_search (%u queries per chunk, %u tiles)", qc, n_tiles);
+        rc = MSR_E_NOMEM;
+    }
+    ScoreArgs sa;
+    sa.seg_ptr = d->d_seg_ptr;
+    sa.postings = d->d_postings;
+    sa.q_meta = reinterpret_cast<const uint4*>(b->d_qptr);
+    sa.q_term = b->d_qterm;
+    sa.q_w = b->d_qw;
+    sa.dense = d->d_dense;
+    sa.q_dense = b->d_qdense;
+    sa.n_pairs = d->n_pairs;
+    sa.part = nullptr;
+    sa.theta = nullptr;
+    sa.unsorted = 0;
+    sa.n_docs = n;
+    sa.vec_base = d->vec_base;
+    sa.n_terms = d->seg_terms;
+    sa.tile0 = 0;
+    sa.tl0 = 0;
+    sa.nq = (uint32_t)nq;
+    sa.k = (uint32_t)k;
+    sa.dump = nullptr;
+    sa.tpr = 1;
+    sa.dump_add = 0;
+    sa.dbg = 0;
+    sa.stamps = nullptr;
+    sa.light = 0;
+    HybridArgs ha;
+    ha.dkeys = d_S;
+    ha.ld = ld;
+    ha.self_ord = d_self;
+    ha.depth = (uint32_t)depth;
+    ha.k = (uint32_t)k;
+    ha.w_dense = alpha;
+    ha.w_sparse = 1.0f - alpha;
+    ha.out_ord = d_ord;
+    ha.out_score = d_sf;
+    ha.out_n = d_n;
+    ha.qlist = nullptr;
+    ha.cand_s = d_cs;
+    ha.cand_d = d_cd;
+    ha.tile_meta = d_meta;
+    ha.n_tiles = n_tiles;
+    ha.stride = quota_full;
+    ha.quota_full = quota_full;
+    ha.quota_last = quota_last;
+    ha.flags = d_flags;
+    // one pass of the three kernels over `rows` launch rows (queries q0 .. or the listed ones), dense rows from d_Qrows
+    auto launch_rows = [&](const _Float16* d_Qrows, uint32_t rows, uint32_t q0, hipEvent_t* e) -> int {
+        const uint32_t rows_pad = (rows + 255) / 256 * 256;
+        if (e) (void)hipEventRecord(e[0], d->stream);
+        int r2 = launch_dense_gemm(dx, dx->d_P_ord, d_Qrows, d_S, rows, rows_pad, n_cover, ld, d->stream, true, true);
+        if (r2 != MSR_OK) return r2;
+        if (e) (void)hipEventRecord(e[1], d->stream);
+        sa.q0 = q0;
+        sa.qn = rows;
+        for (uint32_t t0 = 0; t0 < n_tiles; t0 += kMaxGridY) {  // (grid y limit; tile_l = blockIdx.y needs t0 == 0)
+            if (t0) {
+                set_error("msr_hybrid_search: more than %u tiles", kMaxGridY);
+                return MSR_E_RANGE;
+            }
+            const dim3 grid(rows, n_tiles);
+            if (tile == 4096)
+                hipLaunchKernelGGL((hybrid_tiles<4096, 256, 4, 5, false, 1>), grid, dim3(256), 0, d->stream, sa, ha);
+            else
+                hipLaunchKernelGGL((hybrid_tiles<8192, 512, 4, 6, false, 1>), grid, dim3(512), 0, d->stream, sa, ha);
+        }
+        if (hipGetLastError() != hipSuccess) {
+            set_error("hybrid_tiles launch failed: %s", hipGetErrorString(hipGetLastError()));
+            return MSR_E_HIP;
+        }
+        if (e) (void)hipEventRecord(e[2], d->stream);
+        hipLaunchKernelGGL((hybrid_fuse_query<256>), dim3(rows), dim3(256), 0, d->stream, ha, q0);
+        if (hipGetLastError() != hipSuccess) {
+            set_error("hybrid_fuse_query launch failed: %s", hipGetErrorString(hipGetLastError()));
+            return MSR_E_HIP;
+        }
+        if (e) (void)hipEventRecord(e[3], d->stream);
+        return MSR_OK;
+    };
+    std::vector<hipEvent_t> ev;
+    auto four_events = [&]() -> hipEvent_t* {
+        const size_t at = ev.size();
+        for (int i = 0; i < 4; ++i) {
+            hipEvent_t x = nullptr;
+            if (!d->spare_events.empty()) {
+                x = d->spare_events.back();
+                d->spare_events.pop_back();
+            } else if (hipEventCreate(&x) != hipSuccess) {
+                x = nullptr;
+            }
+            ev.push_back(x);
+        }
+        for (size_t i = at; i < ev.size(); ++i)
+            if (!ev[i]) return nullptr;
+        return ev.data() + at;
+    };
+    ev.reserve(4 * ((size_t)nq / std::max<uint32_t>(qc, 1) + 4) + 64);  // (pointers into ev stay valid)
+    for (uint32_t q0 = 0; q0 < (uint32_t)nq && rc == MSR_OK; q0 += qc) {
+        const uint32_t qn = std::min<uint32_t>(qc, (uint32_t)nq - q0);
+        hipEvent_t* e = four_events();
+        if (!e) {
+            set_error("hipEventCreate failed");
+            rc = MSR_E_HIP;
+            break;
+        }
+        rc = launch_rows(d_Q + (size_t)q0 * dx->h, qn, q0, e);
+    }
+    std::vector<uint32_t> hflags((size_t)nq, 0);
+    if (rc == MSR_OK && nq &&
+        (hipMemcpyAsync(hflags.data(), d_flags, (size_t)nq * 4, hipMemcpyDeviceToHost, d->stream) != hipSuccess ||
+         hipStreamSynchronize(d->stream) != hipSuccess)) {
+        set_error("hybrid kernels failed: %s", hipGetErrorString(hipGetLastError()));
+        rc = MSR_E_HIP;
+    }
+    // ---- second round (normally empty): the flagged queries again, every tile emitting its own top-depth
+    std::vector<uint32_t> redo;
+    for (int i = 0; i < nq && rc == MSR_OK; ++i)
+        if (hflags[(size_t)i]) redo.push_back((uint32_t)i);
+    static const bool dbg = getenv("MSR_DEBUG_HYBRID") != nullptr;
+    if (dbg) fprintf(stderr, "[msr] hybrid multi-tile: %u tiles, quota %u / %u of depth %d, %u queries per chunk, %zu of %d "
+                             "queries repeated with quota = depth\n", n_tiles, quota_full, quota_last, depth, qc, redo.size(), nq);
+    if (rc == MSR_OK && !redo.empty()) {
+        const uint32_t rows_cap = (uint32_t)std::min<size_t>(std::min<size_t>(cand_slots / (per_tile_row * (size_t)depth), qc), redo.size());
+        std::vector<uint16_t> qrows((size_t)rows_cap * dx->h);
+        ha.stride = ha.quota_full = ha.quota_last = (uint32_t)depth;
+        ha.qlist = d_qlist;
+        for (size_t at = 0; at < redo.size() && rc == MSR_OK; at += rows_cap) {
+            const uint32_t rows = (uint32_t)std::min<size_t>(rows_cap, redo.size() - at);
+            const uint32_t rows_pad = (rows + 255) / 256 * 256;
+            for (uint32_t r = 0; r < rows; ++r)
+                memcpy(qrows.data() + (size_t)r * dx->h, q_fp16 + (size_t)redo[at + r] * dx->h, (size_t)dx->h * 2);
+            // (d_Q's first rows are reused: the first round is over)
+            ok = hipMemsetAsync(d_Q, 0, (size_t)rows_pad * dx->h * 2, d->stream) == hipSuccess &&
+                 hipMemcpyAsync(d_Q, qrows.data(), (size_t)rows * dx->h * 2, hipMemcpyHostToDevice, d->stream) == hipSuccess &&
+                 hipMemcpyAsync(d_qlist, redo.data() + at, (size_t)rows * 4, hipMemcpyHostToDevice, d->stream) == hipSuccess;
+            if (!ok) {
+                set_error("upload failed in the second round of msr_hybrid_search");
+                rc = MSR_E_HIP;
+                break;
+            }
+            hipEvent_t* e = ev.size() + 4 <= ev.capacity() ? four_events() : nullptr;
+            rc = launch_rows(d_Q, rows, 0, e);
+            if (rc == MSR_OK && hipStreamSynchronize(d->stream) != hipSuccess) {  // (qrows / redo are re-filled next)
+                set_error("hybrid kernels failed in the second round: %s", hipGetErrorString(hipGetLastError()));
+                rc = MSR_E_HIP;
+            }
+        }
+        if (rc == MSR_OK) {  // with quota = depth every list is complete by construction
+            (void)hipMemcpy(hflags.data(), d_flags, (size_t)nq * 4, hipMemcpyDeviceToHost);
+            for (uint32_t i : redo)
+                if (hflags[i]) {
+                    set_error("internal error: query %u still incomplete after the second round", i);
+                    rc = MSR_E_HIP;
+                    break;
+                }
+        }
+    }
+    float t_gemm = 0, t_cand = 0, t_fuse = 0;
+    if (rc == MSR_OK) {
+        for (size_t i = 0; i + 3 < ev.size(); i += 4) {
+            float a = 0, c = 0, f = 0;
+            (void)hipEventElapsedTime(&a, ev[i], ev[i + 1]);
+            (void)hipEventElapsedTime(&c, ev[i + 1], ev[i + 2]);
+            (void)hipEventElapsedTime(&f, ev[i + 2], ev[i + 3]);
+            t_gemm += a;
+            t_cand += c;
+            t_fuse += f;
+        }
+        if (nq && (hipMemcpy(out_ord, d_ord, (size_t)nq * k * 4, hipMemcpyDeviceToHost) != hipSuccess ||
+                   hipMemcpy(out_score, d_sf, (size_t)nq * k * 4, hipMemcpyDeviceToHost) != hipSuccess ||
+                   hipMemcpy(out_n, d_n, (size_t)nq * 4, hipMemcpyDeviceToHost) != hipSuccess)) {
+            set_error("download failed in msr_hybrid_search");
+            rc = MSR_E_HIP;
+        }
+    }
+    if (ms) {
+        ms[0] = t_cand;
+        ms[1] = t_gemm;
+        ms[2] = 0.f;
+        ms[3] = t_fuse;
+    }
+    for (hipEvent_t x : ev) {
+        if (!x) continue;
+        if (d->spare_events.size() < 64)
+            d->spare_events.push_back(x);
+        else
+            (void)hipEventDestroy(x);
+    }
+    batch_free(b);
+    return rc;
+}
+
 extern "C" {
 
 int msr_hybrid_search(msr_index* ix, msr_dense* dx, const int64_t* q_ptr, const int32_t* q_term, const int32_t* q_w,
@@ -1502,6 +2130,10 @@ int msr_hybrid_search(msr_index* ix, msr_dense* dx, const int64_t* q_ptr, const 
         (h->tile_docs == 4096 || h->tile_docs == 8192))
         return hybrid_search_fused(ix, dx, q_ptr, q_term, q_w, q_fp16, nq, depth, k, alpha, flags, row2ord, self_ord,
                                    out_ord, out_score, out_n, ms);
+    if (!no_fused && ix->shard_ntiles == h->n_tiles && ix->term_nshards == 0 && dx->h % 8 == 0 && h->n_tiles <= kMaxGridY &&
+        (h->tile_docs == 4096 || h->tile_docs == 8192))
+        return hybrid_search_multitile(ix, dx, q_ptr, q_term, q_w, q_fp16, nq, depth, k, alpha, flags, row2ord, self_ord,
+                                       out_ord, out_score, out_n, ms);
     msr_batch* b = nullptr;
     int rc = msr_batch_create(ix, q_ptr, q_term, q_w, nq, depth, flags, &b);
     if (rc != MSR_OK) return rc;

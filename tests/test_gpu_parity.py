@@ -923,6 +923,212 @@ def test_fused_hybrid_randomised(m, tmp_path):
         os.remove(path)
 
 
+def _hybrid_case(m, tmp_path, n, tile, nq, depth, k, alpha, remove, h=64, n_terms=2000, seed=0, doc_nnz=48, q_nnz=30,
+                 expect="multi"):
+    """One corpus through msr_hybrid_search against the oracle pipeline, every query."""
+    from mllm_sparse_retrieval_amd.dense import DenseIndex, hybrid_search, row_to_ordinal
+
+    docs, (qp, qt, qw) = helpers.synth(n, doc_nnz, nq, q_nnz, n_terms, seed=seed or (n + depth))
+    rng = np.random.default_rng(n + 7)
+    ids = [str(int(x)) for x in rng.permutation(3 * n)[:n]]       # ids in no particular order: ordinals != rows
+    path = m.build_index_from_csr(str(tmp_path / "mt.idx"), *docs, n_terms, doc_ids=ids, tile_docs=tile)
+    p, q = _unit_rows(rng, n, h), _unit_rows(rng, nq, h)
+    qids = [ids[i] for i in range(nq)]                             # query ids that ARE doc ids (remove_query matters)
+    with m.SparseIndex(path, device=0) as ix:
+        dix = DenseIndex(p)
+        r2o = row_to_ordinal(ix, ids)
+        self_ord = np.array([int(r2o[i]) for i in range(nq)], dtype=np.int32) if remove else None
+        ords, fs, cnt, ms = hybrid_search(ix, dix, qp, qt, qw, q, depth, k, alpha, r2o, self_ord)
+        if expect == "multi":   # hybrid_tiles<MODE 1> + hybrid_fuse_query: {candidates, GEMM, 0, fusion}
+            assert ms["sparse"] > 0 and ms["dense_gemm"] > 0 and ms["dense_select"] == 0 and ms["fusion"] > 0
+        want, sq = helpers.oracle_hybrid(docs, n_terms, ids, qp, qt, qw, q, p, depth, alpha, np.arange(nq), remove, qids,
+                                         dense_tie_key=r2o)
+        helpers.assert_hybrid_matches(want, sq, np.arange(nq), ords, fs, cnt, ix.docid, k)
+        if remove:
+            assert all(qids[i] not in [ix.docid(int(o)) for o in ords[i, :cnt[i]]] for i in range(nq))
+        n_tiles = ix.n_tiles
+        dix.close()
+    return n_tiles
+
+
+@pytest.mark.parametrize("n,tile,depth,k,alpha,remove", [(9000, 0, 300, 10, 0.5, False), (20000, 4096, 1000, 64, 0.3, True),
+                                                       (25010, 0, 1000, 200, 0.5, True), (8200, 8192, 1024, 1024, 0.7, False),
+                                                       (12000, 4096, 50, 1, 0.0, True), (16385, 8192, 7, 5, 1.0, False),
+                                                       (5000, 0, 1000, 200, 0.5, True)])
+def test_multitile_hybrid_vs_oracle_pipeline(m, tmp_path, n, tile, depth, k, alpha, remove):
+    """Multi-tile indexes (and k > 64 on one tile) through the candidate kernels: hybrid_tiles<MODE 1> emits every tile's
+    quota of candidates per side, hybrid_fuse_query finds both depth-th bests, fuses and ranks. Against the oracle pipeline
+    (C oracle sparse + numpy dense -> oracle.get_run_dict -> oracle.fuse, pinned to src/hybrid.py:32-53), every query:
+    the reference's own hybrid shape in small (25 010 docs, depth 1000, remove_query, scripts/search.sh:25-27), the
+    recall reporter's k = 200 (src/metrices.py:9), k = depth = 1024, a last tile of one doc, alpha at both ends."""
+    tiles = _hybrid_case(m, tmp_path, n, tile, 60, depth, k, alpha, remove)
+    assert tiles == (n + (tile or 8192) - 1) // (tile or 8192)
+
+
+def test_multitile_hybrid_second_round(m, tmp_path, monkeypatch):
+    """A quota too small for the depth lists (forced through MSR_HYBRID_QUOTA): hybrid_fuse_query flags every query and
+    the second round (every tile emits its own top-depth) produces the same exact result; and sparse lists that live in
+    ONE tile (the queries' terms occur only in the first 300 ordinals), which no share-based quota covers."""
+    monkeypatch.setenv("MSR_HYBRID_QUOTA", "3")
+    _hybrid_case(m, tmp_path, 20000, 4096, 40, 400, 10, 0.5, True)
+    monkeypatch.delenv("MSR_HYBRID_QUOTA")
+    from mllm_sparse_retrieval_amd.dense import DenseIndex, hybrid_search, row_to_ordinal
+
+    n, nq, n_terms, h, depth, k = 18000, 30, 500, 32, 250, 10
+    rng = np.random.default_rng(5)
+    # docs 0 .. 299 (ids "00000" .. = the lowest ordinals: one tile) hold terms 0-99, all other docs terms 100-499
+    nnz = 20
+    dp = np.arange(0, n * nnz + 1, nnz, dtype=np.uint64)
+    dt = np.concatenate([rng.choice(100, nnz, replace=False) if i < 300 else 100 + rng.choice(400, nnz, replace=False)
+                         for i in range(n)]).astype(np.uint32)
+    dw = rng.integers(1, 300, n * nnz).astype(np.uint32)
+    ids = [f"{i:05d}" for i in range(n)]
+    qp = np.arange(nq + 1, dtype=np.int64) * 10
+    qt = rng.integers(0, 100, nq * 10).astype(np.int32)
+    qw = rng.integers(1, 50, nq * 10).astype(np.int32)
+    path = m.build_index_from_csr(str(tmp_path / "one.idx"), dp, dt, dw, n_terms, doc_ids=ids, tile_docs=4096)
+    p, q = _unit_rows(rng, n, h), _unit_rows(rng, nq, h)
+    with m.SparseIndex(path, device=0) as ix:
+        dix = DenseIndex(p)
+        r2o = row_to_ordinal(ix, ids)
+        ords, fs, cnt, ms = hybrid_search(ix, dix, qp, qt, qw, q, depth, k, 0.5, r2o)
+        want, sq = helpers.oracle_hybrid((dp, dt, dw), n_terms, ids, qp, qt, qw, q, p, depth, 0.5, np.arange(nq),
+                                         dense_tie_key=r2o)
+        helpers.assert_hybrid_matches(want, sq, np.arange(nq), ords, fs, cnt, ix.docid, k)
+        dix.close()
+
+
+def test_hybrid_reference_shape_i2t_full(m, tmp_path):
+    """The reference's OWN hybrid run at its real shape (scripts/search.sh:5,16-33: TARGET_TYPE=text, --query_type
+    image, --depth 1000, --remove_query, --alpha 0.5; COCO-5K test split): 5 000 image queries over 25 010 caption docs,
+    H = 4096, fused top-10. All queries run on the GPU; every 25th is checked against the oracle pipeline (ids equal up
+    to 2e-6 near-ties, fused scores within 1e-5) — once through the candidate kernels and once through the list-based
+    path (score_tiles / select_tiles / fuse_tiles), which has to give the same answer."""
+    import subprocess
+    import sys
+
+    from mllm_sparse_retrieval_amd import workloads
+    from mllm_sparse_retrieval_amd.dense import DenseIndex, hybrid_search, row_to_ordinal
+
+    n, nq, h, depth, k, alpha, n_terms = 25010, 5000, 4096, 1000, 10, 0.5, 30000
+    docs, (qp, qt, qw), p, q = workloads.hybrid_vectors(n, nq, h)
+    ids = [str(i) for i in range(n)]
+    path = m.build_index_from_csr(str(tmp_path / "i2t.idx"), *docs, n_terms, doc_ids=ids)
+    sample = np.arange(0, nq, 25)
+    qids = [str(i) for i in range(nq)]                          # image ids collide with caption ids: remove_query acts
+    with m.SparseIndex(path, device=0) as ix:
+        assert ix.n_tiles == 4
+        dix = DenseIndex(p)
+        r2o = row_to_ordinal(ix, ids)
+        self_ord = r2o[:nq].astype(np.int32)
+        ords, fs, cnt, ms = hybrid_search(ix, dix, qp, qt, qw, q, depth, k, alpha, r2o, self_ord)
+        assert ms["dense_select"] == 0 and ms["fusion"] > 0   # the candidate kernels ran
+        want, sq = helpers.oracle_hybrid(docs, n_terms, ids, qp, qt, qw, q, p, depth, alpha, sample, True, qids,
+                                         dense_tie_key=r2o)
+        helpers.assert_hybrid_matches(want, sq, sample, ords, fs, cnt, ix.docid, k)
+        assert all(qids[i] not in [ix.docid(int(o)) for o in ords[i, :cnt[i]]] for i in sample)
+        dix.close()
+    np.savez(tmp_path / "got.npz", ords=ords, fs=fs, cnt=cnt)
+    # the list-based path in a child process (the switch is read once per process)
+    code = f"""
+import sys, numpy as np
+sys.path.insert(0, {os.path.dirname(os.path.dirname(os.path.abspath(__file__)))!r})
+import mllm_sparse_retrieval_amd as m
+from mllm_sparse_retrieval_amd import workloads
+from mllm_sparse_retrieval_amd.dense import DenseIndex, hybrid_search, row_to_ordinal
+docs, (qp, qt, qw), p, q = workloads.hybrid_vectors({n}, {nq}, {h})
+with m.SparseIndex({path!r}, device=0) as ix:
+    dix = DenseIndex(p)
+    r2o = row_to_ordinal(ix, [str(i) for i in range({n})])
+    ords, fs, cnt, ms = hybrid_search(ix, dix, qp, qt, qw, q, {depth}, {k}, {alpha}, r2o, r2o[:{nq}].astype(np.int32))
+    assert ms["dense_select"] > 0, ms
+    dix.close()
+np.savez({str(tmp_path / "list.npz")!r}, ords=ords, fs=fs, cnt=cnt)
+"""
+    subprocess.run([sys.executable, "-c", code], check=True, env=dict(os.environ, MSR_NO_FUSED_HYBRID="1"))
+    lst = np.load(tmp_path / "list.npz")
+    with m.SparseIndex(path, device=-1) as ixh:
+        helpers.assert_hybrid_matches(want, sq, sample, lst["ords"], lst["fs"], lst["cnt"], ixh.docid, k)
+    # the two paths agree on every query up to near-ties (dense ties at the depth boundary: ordinal vs row rule)
+    same = (lst["ords"] == ords).all(axis=1)
+    assert same.mean() > 0.99 and np.abs(lst["fs"] - fs).max() <= 1e-5
+
+
+def test_hybrid_without_inner_events_returns_results(m, tmp_path):
+    """MSR_HYBRID_NO_INNER_EVENTS (a documented diagnostic switch) only drops the per-chunk laps: the results must come
+    back all the same (round 2's advisor finding: the download sat inside the timing branch)."""
+    import subprocess
+    import sys
+
+    code = f"""
+import sys, numpy as np
+sys.path.insert(0, {os.path.dirname(os.path.dirname(os.path.abspath(__file__)))!r})
+import mllm_sparse_retrieval_amd as m
+from tests import helpers
+from mllm_sparse_retrieval_amd.dense import DenseIndex, hybrid_search, row_to_ordinal
+docs, (qp, qt, qw) = helpers.synth(3000, 48, 50, 30, 2000, seed=3)
+rng = np.random.default_rng(3)
+p = rng.standard_normal((3000, 64)).astype(np.float32); q = rng.standard_normal((50, 64)).astype(np.float32)
+path = m.build_index_from_csr({str(tmp_path / "e.idx")!r}, *docs, 2000)
+with m.SparseIndex(path, device=0) as ix:
+    dix = DenseIndex(p)
+    r2o = row_to_ordinal(ix, [str(i) for i in range(3000)])
+    ords = np.full((50, 10), 12345, np.uint32)
+    o, f, c, ms = hybrid_search(ix, dix, qp, qt, qw, q, 300, 10, 0.5, r2o)
+    dix.close()
+np.savez(sys.argv[1], o=o, f=f, c=c)
+"""
+    outs = []
+    for name, extra in (("a.npz", {}), ("b.npz", {"MSR_HYBRID_NO_INNER_EVENTS": "1"})):
+        subprocess.run([sys.executable, "-c", code, str(tmp_path / name)], check=True, env=dict(os.environ, **extra))
+        outs.append(np.load(tmp_path / name))
+    assert (outs[0]["c"] == 10).all()
+    for key in ("o", "f", "c"):
+        assert (outs[0][key] == outs[1][key]).all(), key
+
+
+def test_fused_hybrid_tightly_clustered_scores(m, tmp_path):
+    """Scores far from 0 with a tiny spread (round 2's advisor finding: a histogram offset rounded in f32 put the top bin
+    past the array): sparse scores 2e7 + [1, 300] (one heavy term almost every doc holds), and dense scores
+    138.5 + j * 2^-16 for j in 0..3 (exactly representable: ties in blocks, cut by ordinal). Each side is checked through
+    a list only IT fills: an empty sparse query (union = the dense depth list) and alpha = 0 with depth-limited sparse."""
+    from mllm_sparse_retrieval_amd.dense import DenseIndex, hybrid_search, row_to_ordinal
+
+    n, V, h, nq, depth, k = 3000, 50, 32, 24, 50, 64
+    rng = np.random.default_rng(9)
+    # every doc but the last holds term 0 with weight 40 000; every doc holds one light term 1 .. 49 with weight 1 .. 300
+    dp = np.concatenate([np.arange(0, 2 * (n - 1) + 1, 2), [2 * (n - 1) + 1]]).astype(np.uint64)
+    dt = np.concatenate([np.stack([np.zeros(n - 1, np.uint32), rng.integers(1, V, n - 1).astype(np.uint32)], 1).ravel(),
+                         [1]]).astype(np.uint32)
+    dw = np.concatenate([np.stack([np.full(n - 1, 40000, np.uint32), rng.integers(1, 301, n - 1).astype(np.uint32)], 1).ravel(),
+                         [5]]).astype(np.uint32)
+    ids = [str(i) for i in range(n)]
+    path = m.build_index_from_csr(str(tmp_path / "cl.idx"), dp, dt, dw, V, doc_ids=ids)
+    # queries 0-11: term 0 x 500 + every light term x 1 (scores 2e7 + light weight); queries 12-23: empty
+    qterms = np.concatenate([[0], np.arange(1, V)]).astype(np.int32)
+    qweights = np.concatenate([[500], np.ones(V - 1)]).astype(np.int32)
+    qp = np.concatenate([np.arange(13) * V, np.full(12, 12 * V)]).astype(np.int64)
+    qt, qw = np.tile(qterms, 12), np.tile(qweights, 12)
+    p = np.zeros((n, h), np.float32)
+    p[:, 0] = 1.0
+    p[:, 1] = (np.arange(n) % 4) * 2.0 ** -10
+    q = np.zeros((nq, h), np.float32)
+    q[:, 0] = 138.5
+    q[:, 1] = 2.0 ** -6
+    with m.SparseIndex(path, device=0) as ix:
+        dix = DenseIndex(p)
+        r2o = row_to_ordinal(ix, ids)
+        for alpha in (0.0, 1.0, 0.5):
+            ords, fs, cnt, ms = hybrid_search(ix, dix, qp, qt, qw, q, depth, k, alpha, r2o)
+            want, sq = helpers.oracle_hybrid((dp, dt, dw), V, ids, qp, qt, qw, q, p, depth, alpha, np.arange(nq),
+                                             dense_tie_key=r2o)
+            # the union of two depth-50 lists: at most 100 docs, exactly 50 for the empty queries — a threshold that came
+            # out too low would fill all 64 places
+            assert (cnt[12:] == depth).all()
+            helpers.assert_hybrid_matches(want, sq, np.arange(nq), ords, fs, cnt, ix.docid, k)
+        dix.close()
+
+
 def test_fused_hybrid_mass_ties(m, tmp_path):
     """Every doc holds the same term with the same weight: all sparse scores tie, so the sparse top-`depth` list is the
     `depth` LOWEST ordinals (doc-id string order) — the selection's histogram collapses into one bin and has to split
