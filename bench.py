@@ -19,7 +19,9 @@ Extra objects (never part of `value`):
   "c4_1m"      configs[3], the north-star target: 1 M docs / 10 000 queries; at N > 1 the index is doc-range sharded over
                the ranks and the per-shard top-k lists are merged after ONE RCCL all-gather (exact), "scaling": "strong";
                plus the literal term-range partition (every rank resident with its own term range only).
-  "c5_hybrid"  configs[4]: dense fp16 MFMA + sparse + min-max fusion, 1 GPU.
+  "c5_hybrid"  configs[4]: dense fp16 MFMA + sparse + min-max fusion, 1 GPU (COCO-5K text->image: 5 000 docs, one tile).
+  "c5_hybrid_i2t"  the same search at the shape the reference's own hybrid script runs (scripts/search.sh: 25 010 caption
+               docs, 5 000 image queries, --remove_query): four tiles.
 
 Failure policy: a rank that cannot get its own GPU, an RCCL communicator that does not come up (unless
 --allow-gloo-fallback), or an exchange that does not finish within --c4-timeout end the run with a NON-ZERO status;
@@ -95,7 +97,9 @@ def parse_args(argv):
     ap.add_argument("--only-c4", action="store_true", help="(profiling) run only the 1 M-doc workload")
     ap.add_argument("--c5-docs", type=int, default=5000)
     ap.add_argument("--c5-queries", type=int, default=25010)
-    ap.add_argument("--no-c5", action="store_true", help="skip the hybrid (config 5) extra object")
+    ap.add_argument("--no-c5", action="store_true", help="skip the hybrid (config 5) extra objects")
+    ap.add_argument("--c5-shape", choices=["both", "t2i", "i2t"], default="both",
+                    help="(profiling) one hybrid shape only: t2i = configs[4], i2t = the reference's own script")
     ap.add_argument("--only-c5", action="store_true", help="(profiling) run only the hybrid workload")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline / parity samples")
     ap.add_argument("--cpu-seconds", type=float, default=8.0, help="CPU work per baseline row (s)")
@@ -727,10 +731,11 @@ def run_c4(args, ranks, m, wlmod, status):
     return out
 
 
-def c5_parity_sample(m, docs, n_terms, qp, qt, qw, p, q, depth, k, alpha, got, every):
+def c5_parity_sample(m, docs, n_terms, qp, qt, qw, p, q, depth, k, alpha, got, every, remove_query=False, tie_key=None):
     """GPU hybrid results of every `every`-th query against the ORACLE pipeline: C oracle sparse top-depth + numpy
     dense top-depth on the fp16-rounded inputs -> oracle.get_run_dict -> oracle.fuse (pinned to src/hybrid.py:32-53)
-    -> top-k. Fused scores within 1e-5; ids equal except near-ties (2e-6)."""
+    -> top-k. Fused scores within 1e-5; ids equal except near-ties (2e-6). Query i carries the id str(i) (= a doc id:
+    remove_query skips that doc, src/search.py:72-74); tie_key = the order that cuts exact dense ties (doc ordinals)."""
     from oracle import oracle, taat
 
     ords, fs, cnt, docid_of = got
@@ -743,12 +748,13 @@ def c5_parity_sample(m, docs, n_terms, qp, qt, qw, p, q, depth, k, alpha, got, e
     sp = np.concatenate([[0], np.cumsum(qp[sample + 1] - qp[sample])]).astype(np.int64)
     wo, wsc, wn = oix.search(sp, qt[sel], qw[sel], depth, threads=16)
     s = q[sample].astype(np.float16).astype(np.float32) @ p.astype(np.float16).astype(np.float32).T
-    didx = np.lexsort((np.broadcast_to(np.arange(n), s.shape), -s), axis=1)[:, :depth]
+    tk = np.arange(n) if tie_key is None else np.asarray(tie_key, dtype=np.int64)
+    didx = np.lexsort((np.broadcast_to(tk, s.shape), -s), axis=1)[:, :depth]
     dsc = np.take_along_axis(s, didx, axis=1)
     qids = [str(int(i)) for i in sample]
     o_sparse = oracle.get_run_dict(qids, [[float(np.float32(x)) for x in wsc[j, :wn[j]]] for j in range(len(sample))],
-                                   [[sorted_ids[int(d)] for d in wo[j, :wn[j]]] for j in range(len(sample))], False)
-    o_dense = oracle.get_run_dict(qids, dsc, np.array([[ids[j] for j in row] for row in didx]), False)
+                                   [[sorted_ids[int(d)] for d in wo[j, :wn[j]]] for j in range(len(sample))], remove_query)
+    o_dense = oracle.get_run_dict(qids, dsc, np.array([[ids[j] for j in row] for row in didx]), remove_query)
     want = oracle.fuse([o_dense, o_sparse], [alpha, 1 - alpha])
     worst, id_mism, near_tie_swaps = 0.0, 0, 0
     for j, i in enumerate(sample):
@@ -769,44 +775,57 @@ def c5_parity_sample(m, docs, n_terms, qp, qt, qw, p, q, depth, k, alpha, got, e
             "checker": "oracle pipeline: oracle_taat.c + numpy dense on fp16-rounded inputs + oracle.fuse"}
 
 
-def run_c5(args, ranks, m):
-    """configs[4]: hybrid dense + sparse, COCO-5K t->i shape: N = 5 000 docs (128 nnz + 4096-d fp16 unit vectors),
-    25 010 queries (120 nnz + 4096-d), depth 1000 -> fused top-10, alpha 0.5 (scripts/search.sh:25,32). One GPU."""
+def run_c5(args, ranks, m, wlmod, shape="t2i"):
+    """Hybrid dense + sparse search, H = 4096, depth 1000 -> fused top-10, alpha 0.5 (scripts/search.sh:25,32). One GPU.
+    shape "t2i" = BASELINE configs[4] (COCO-5K text->image): 5 000 image docs, 25 010 caption queries: one tile, one
+        fused kernel per query (hybrid_tiles).
+    shape "i2t" = the run the reference's own script does (scripts/search.sh:5,26-27: TARGET_TYPE=text, --query_type
+        image, --remove_query): 25 010 caption docs, 5 000 image queries: four tiles, the candidate kernels
+        (hybrid_tiles<MODE 1> per (tile, query) + hybrid_fuse_query per query)."""
     from mllm_sparse_retrieval_amd.dense import DenseIndex, hybrid_search, row_to_ordinal
 
-    n, nq, h, depth, k, alpha, n_terms = args.c5_docs, args.c5_queries, 4096, 1000, 10, 0.5, 30000
-    docs = m.synth_vectors(n, 128, n_terms, seed=4, threads=args.host_threads)
-    qp, qt, qw = m.synth_vectors(nq, 120, n_terms, seed=5, threads=args.host_threads)
-    qp, qt, qw = qp.astype(np.int64), qt.astype(np.int32), qw.astype(np.int32)
-    rng = np.random.default_rng(4)
-    p = rng.standard_normal((n, h), dtype=np.float32)
-    p /= np.linalg.norm(p, axis=1, keepdims=True)
-    q = rng.standard_normal((nq, h), dtype=np.float32)
-    q /= np.linalg.norm(q, axis=1, keepdims=True)
+    h, depth, k, alpha, n_terms = 4096, 1000, 10, 0.5, 30000
+    n, nq = (args.c5_docs, args.c5_queries) if shape == "t2i" else (args.c5_queries, args.c5_docs)
+    remove = shape == "i2t"
+    wname = "c5_hybrid" if shape == "t2i" else "c5_hybrid_i2t"
+    docs, (qp, qt, qw), p, q = wlmod.hybrid_vectors(n, nq, h, n_terms, seed=4, threads=args.host_threads)
     tmp = tempfile.mkdtemp(prefix="msr_c5_")
     path = m.build_index_from_csr(os.path.join(tmp, "c5.idx"), *docs, n_terms, threads=args.host_threads)
     ix = m.SparseIndex(path, device=ranks.local_rank)
     dix = DenseIndex(p, device=ranks.local_rank)
     r2o = row_to_ordinal(ix, [str(i) for i in range(n)])
-    phase("c5 hybrid search")
-    hybrid_search(ix, dix, qp, qt, qw, q, depth, k, alpha, r2o)                      # warm-up
+    self_ord = r2o[:nq].astype(np.int32) if remove else None   # query i carries the id of doc i (remove_query)
+    phase(f"{wname} hybrid search")
+    hybrid_search(ix, dix, qp, qt, qw, q, depth, k, alpha, r2o, self_ord)                      # warm-up
     t0 = time.perf_counter()
-    ords, fs, cnt, ms = hybrid_search(ix, dix, qp, qt, qw, q, depth, k, alpha, r2o)
+    ords, fs, cnt, ms = hybrid_search(ix, dix, qp, qt, qw, q, depth, k, alpha, r2o, self_ord)
     wall = time.perf_counter() - t0
     kern = sum(ms.values())
     flops = 2.0 * nq * n * h
-    fused = ms["dense_select"] == 0 and ms["fusion"] == 0  # single-tile index: hybrid_tiles does everything but the GEMM
-    kernel_ms = ({"hybrid_tiles": round(ms["sparse"], 3), "dense_gemm": round(ms["dense_gemm"], 3)} if fused
-                 else {k2: round(v, 3) for k2, v in ms.items()})
+    fused = ms["dense_select"] == 0 and ms["fusion"] == 0     # one tile: hybrid_tiles does everything but the GEMM
+    multi = ms["dense_select"] == 0 and ms["fusion"] > 0      # several tiles: candidate kernel + per-query fusion kernel
+    if fused:
+        kernel_ms = {"hybrid_tiles": round(ms["sparse"], 3), "dense_gemm": round(ms["dense_gemm"], 3)}
+        pipeline = ("dense_scores_256k (fp16 MFMA GEMM, 16x16x32, four waves of 128x128, on the ordinal-ordered passage "
+                    "matrix, query chunks of ~160 MB of score rows) -> hybrid_tiles (one workgroup per query: sparse "
+                    f"scores in LDS, both depth-{depth} memberships by one histogram pass, min-max fusion, top-{k})")
+    elif multi:
+        kernel_ms = {"hybrid_tiles_mode1": round(ms["sparse"], 3), "dense_gemm": round(ms["dense_gemm"], 3),
+                     "hybrid_fuse_query": round(ms["fusion"], 3)}
+        pipeline = ("dense_scores_256k (as above) -> hybrid_tiles<MODE 1> (one workgroup per (tile, query): sparse scores "
+                    "in LDS, the tile's quota of candidates for both depth lists by one histogram pass) -> "
+                    f"hybrid_fuse_query (one workgroup per query: both depth-{depth}-th bests among the candidates by "
+                    f"radix select, verified against every tile's weakest candidate, fusion in an LDS hash table, top-{k}); "
+                    "flagged queries (none here) are repeated with quota = depth")
+    else:
+        kernel_ms = {k2: round(v, 3) for k2, v in ms.items()}
+        pipeline = "list-based: score_tiles + dense GEMM + select_tiles + fuse_tiles + merges"
     out = {"workload": f"hybrid: {n} docs x (128 nnz + {h}-d fp16), {nq} queries x (120 nnz + {h}-d), depth {depth} -> "
-                       f"fused top-{k}, alpha {alpha}",
+                       f"fused top-{k}, alpha {alpha}" + (", remove_query" if remove else ""),
            "value": round(nq / (kern * 1e-3), 1), "unit": "queries/s (kernel time, inputs resident)",
            "host_inclusive_queries_per_s": round(nq / wall, 1),
-           "kernel_ms": kernel_ms,
-           "pipeline": ("dense_scores_256k (fp16 MFMA GEMM, 16x16x32, four waves of 128x128, on the ordinal-ordered passage matrix, query chunks of ~160 MB "
-                        "of score rows) -> hybrid_tiles (one workgroup per query: sparse scores in LDS, both depth-"
-                        f"{depth} memberships by one histogram pass, min-max fusion, top-{k})") if fused else
-                       "list-based: score_tiles + dense GEMM + select_tiles + fuse_tiles + merges (multi-tile index)",
+           "kernel_ms": kernel_ms, "n_tiles": ix.n_tiles,
+           "pipeline": pipeline,
            "dense_tflops": round(flops / (ms["dense_gemm"] * 1e-3) / 1e12, 1) if ms["dense_gemm"] > 0 else None,
            "dtype": "f16 in / f32 accumulate (dense), u32 (sparse), f32 (fusion)"}
     # roofline per stage: the GEMM against the dense fp16 MFMA peak; the integer / selection kernels against the
@@ -816,22 +835,24 @@ def run_c5(args, ranks, m):
         tf = flops / (ms["dense_gemm"] * 1e-3) / 1e12
         rl["dense_gemm"] = {"bound": "mfma", "achieved": round(tf, 1), "peak": MFMA_F16_PEAK_TF, "unit": "TFLOP/s",
                             "frac": round(tf / MFMA_F16_PEAK_TF, 4), "kernel_ms": round(ms["dense_gemm"], 4),
-                            **binding_fractions(counters("c5_hybrid", "dense_scores"), ms["dense_gemm"])}
+                            **binding_fractions(counters(wname, "dense_scores"), ms["dense_gemm"])}
     stages = ((("hybrid_tiles", "hybrid_tiles", "sparse"),) if fused else
+              (("hybrid_tiles_mode1", "hybrid_tiles", "sparse"), ("hybrid_fuse_query", "hybrid_fuse_query", "fusion")) if multi else
               (("dense_select", "select_tiles", "dense_select"), ("fusion", "fuse_tiles", "fusion"),
                ("sparse", "score_tiles", "sparse")))
     for stage, kre, key in stages:
         if ms.get(key, 0) > 0:
-            fr = binding_fractions(counters("c5_hybrid", kre), ms[key])
+            fr = binding_fractions(counters(wname, kre), ms[key])
             cands = {b: fr.get(k3) for b, k3 in (("hbm", "hbm_frac"), ("l2", "l2_frac"), ("valu", "valu_busy"))
                      if fr.get(k3) is not None}
             bound = max(cands, key=cands.get) if cands else None
             rl[stage] = {"bound": bound, "frac": cands.get(bound) if bound else None, "kernel_ms": round(ms[key], 4), **fr}
     out["roofline"] = rl
     if not args.no_cpu:
-        phase("c5 parity sample vs the oracle pipeline")
+        phase(f"{wname} parity sample vs the oracle pipeline")
         out["parity"] = c5_parity_sample(m, docs, n_terms, qp, qt, qw, p, q, depth, k, alpha,
-                                         (ords, fs, cnt, ix.docid), every=50)
+                                         (ords, fs, cnt, ix.docid), every=50 if shape == "t2i" else 25,
+                                         remove_query=remove, tie_key=r2o)
     dix.close()
     ix.close()
     try:
@@ -891,11 +912,14 @@ def main():
             out["c3_coco5k"] = {"error": f"{type(e).__name__}: {e}"}
             log(f"[bench] c3_coco5k failed: {out['c3_coco5k']['error']}")
     if ranks.world == 1 and not args.no_c5 and (args.only_c5 or not only):
-        try:
-            out["c5_hybrid"] = run_c5(args, ranks, m)
-        except Exception as e:
-            out["c5_hybrid"] = {"error": f"{type(e).__name__}: {e}"}
-            log(f"[bench] c5_hybrid failed: {out['c5_hybrid']['error']}")
+        for name, shape in (("c5_hybrid", "t2i"), ("c5_hybrid_i2t", "i2t")):
+            if args.c5_shape not in ("both", shape):
+                continue
+            try:
+                out[name] = run_c5(args, ranks, m, wlmod, shape)
+            except Exception as e:
+                out[name] = {"error": f"{type(e).__name__}: {e}"}
+                log(f"[bench] {name} failed: {out[name]['error']}")
     hung = False
     if not args.no_c4 and (args.only_c4 or not only):
         # The extra object must never take the headline NUMBER down: exceptions are caught and recorded, and at N > 1 a

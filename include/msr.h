@@ -133,6 +133,13 @@ int msr_search_csr(msr_index* ix, const int64_t* q_ptr, const int32_t* q_term, c
 int msr_search_text(msr_index* ix, const char* const* queries, int nq, int k, uint32_t flags, uint32_t* out_doc_ord,
                     float* out_score, uint32_t* out_score_u32, int32_t* out_n);
 
+/* The host half of that call on its own: query strings -> CSR of (term id, count), out-of-vocabulary tokens dropped
+ * (what pyserini's query encoding does in Python before Lucene sees the query, behind src/search.py:86-87); for callers
+ * that hand the CSR to msr_hybrid_search / msr_batch_create. q_ptr (nq + 1 entries) is always filled and *n_entries is
+ * set to the number of (term, count) pairs; q_term / q_w are filled when cap >= *n_entries (call with cap = 0 to size). */
+int msr_encode_queries(const msr_index* ix, const char* const* queries, int nq, int64_t* q_ptr, int32_t* q_term,
+                       int32_t* q_w, int64_t cap, int64_t* n_entries);
+
 /* ---- resident batches: the same search with inputs and outputs kept in HBM (benchmark, pipelining) ---- */
 int msr_batch_create(msr_index* ix, const int64_t* q_ptr, const int32_t* q_term, const int32_t* q_w, int nq,
                      int kmax, uint32_t flags, msr_batch** out);

@@ -59,6 +59,7 @@ SYMBOLS = [
     ("msr_docid_str", _I, [_VP, _U32, C.POINTER(_CP)]),
     ("msr_search_csr", _I, [_VP, _VP, _VP, _VP, _I, _I, _U32, _VP, _VP, _VP, _VP]),
     ("msr_search_text", _I, [_VP, _VP, _I, _I, _U32, _VP, _VP, _VP, _VP]),
+    ("msr_encode_queries", _I, [_VP, _VP, _I, _VP, _VP, _VP, C.c_int64, C.POINTER(C.c_int64)]),
     ("msr_batch_create", _I, [_VP, _VP, _VP, _VP, _I, _I, _U32, C.POINTER(_VP)]),
     ("msr_batch_search", _I, [_VP, _I]),
     ("msr_batch_sync", _I, [_VP]),

@@ -111,21 +111,18 @@ def _cmd_search(a):
     from .run import get_run_dict, sparse_search
     from .searcher import JWhiteSpaceAnalyzer, LuceneImpactSearcher
 
-    dense_retriever = p_lookup = q_reps_by_id = None
+    dense_retriever = p_reps = p_lookup = q_reps_by_id = None
     if a.passage_reps is not None:  # dense side of the hybrid search (src/search.py:227-237)
         import glob
 
         import numpy as np
 
-        from .dense import FaissFlatSearcher
         from .run import pickle_load, search_queries
 
         files = sorted(glob.glob(os.path.join(a.passage_reps, "corpus*.pkl")))
         if not files:
             sys.exit(f"search: no corpus*.pkl under {a.passage_reps}")
         p_reps, p_lookup = pickle_load(files[0])     # files written by this package's own encode step
-        dense_retriever = FaissFlatSearcher(p_reps, device=a.device)
-        dense_retriever.add(p_reps)
         q_reps, q_lookup = pickle_load(os.path.join(a.passage_reps, "query.pkl"))
         q_reps_by_id = {str(i): r for i, r in zip(q_lookup, q_reps)}
     # one process per GPU under a launcher (src/search.py:115-129); gloo carries the recall fractions only
@@ -158,18 +155,28 @@ def _cmd_search(a):
     sparse_run, dense_run, fusion_run = {}, {}, {}
     args.batch_size, args.quiet = a.batch_size, True
     t0 = time.time()
-    for i in range(0, len(qids), bs):
-        scores, rankings = sparse_search(searcher, texts[i:i + bs], qids[i:i + bs], args)
-        sparse_run.update(get_run_dict(qids[i:i + bs], scores, rankings, a.remove_query))
-        if dense_retriever is not None:
-            q = np.stack([q_reps_by_id[x] for x in qids[i:i + bs]])
-            q = q / np.maximum(np.linalg.norm(q, axis=1, keepdims=True), 1e-12)        # F.normalize, src/search.py:342
-            d_scores, d_ids = search_queries(dense_retriever, q, p_lookup, args)
-            dense_run.update(get_run_dict(qids[i:i + bs], d_scores, d_ids, a.remove_query))
-    if dense_retriever is not None:
-        from .fusion import fuse
+    if p_reps is not None and not a.host_fusion:
+        # Hybrid on the GPU (the default): this rank's WHOLE query shard in one msr_hybrid_search call — sparse scores,
+        # both depth lists, the reference's fusion (src/hybrid.py:32-53) and the top --fusion_k never leave HBM.
+        sparse_run, dense_run, fusion_run = _hybrid_on_gpu(a, searcher, p_reps, p_lookup, q_reps_by_id, qids, texts)
+    else:
+        if p_reps is not None:  # --host_fusion: the reference's own structure, batch by batch (src/search.py:455-461)
+            from .dense import FaissFlatSearcher
 
-        fusion_run = fuse([dense_run, sparse_run], [a.alpha, 1 - a.alpha])             # src/search.py:455-461
+            dense_retriever = FaissFlatSearcher(p_reps, device=a.device)
+            dense_retriever.add(p_reps)
+        for i in range(0, len(qids), bs):
+            scores, rankings = sparse_search(searcher, texts[i:i + bs], qids[i:i + bs], args)
+            sparse_run.update(get_run_dict(qids[i:i + bs], scores, rankings, a.remove_query))
+            if dense_retriever is not None:
+                q = np.stack([q_reps_by_id[x] for x in qids[i:i + bs]])
+                q = q / np.maximum(np.linalg.norm(q, axis=1, keepdims=True), 1e-12)    # F.normalize, src/search.py:342
+                d_scores, d_ids = search_queries(dense_retriever, q, p_lookup, args)
+                dense_run.update(get_run_dict(qids[i:i + bs], d_scores, d_ids, a.remove_query))
+        if dense_retriever is not None:
+            from .fusion import fuse
+
+            fusion_run = fuse([dense_run, sparse_run], [a.alpha, 1 - a.alpha])         # src/search.py:455-461
     dt = time.time() - t0
     if not a.quiet:
         print(f"search: {len(qids)} queries in {dt:.3f}s ({len(qids) / max(dt, 1e-9):.0f} q/s end-to-end incl. host)")
@@ -185,7 +192,11 @@ def _cmd_search(a):
             if rank == 0:
                 for name in ("sparse.trec", "dense.trec", "fusion.trec"):
                     parts = [os.path.join(a.save_dir, f"{name}.rank{r}") for r in range(world)]
-                    if all(os.path.exists(p) for p in parts):
+                    missing = [p for p in parts if not os.path.exists(p)]
+                    if missing and len(missing) < len(parts):  # (all missing: that run was not produced at all)
+                        print(f"search: WARNING: {name} not joined, rank files missing (one node and a shared --save_dir "
+                              f"are assumed): {missing}", file=sys.stderr)
+                    if not missing:
                         done = set()  # queries an earlier rank's file already holds (the sampler's padded repeats)
                         with open(os.path.join(a.save_dir, name), "w") as out:
                             for p in parts:
@@ -211,6 +222,48 @@ def _cmd_search(a):
         dist.barrier()
 
 
+def _hybrid_on_gpu(a, searcher, p_reps, p_lookup, q_reps_by_id, qids, texts):
+    """search --passage_reps on the GPU: ONE msr_hybrid_search call for the fused run; the sparse and the dense run the
+    reference also reports (src/metrices.py:105-126) come from one whole-shard call each. Returns the three run dicts in
+    the reference's layouts (src/search.py:66-82; the fused run without the 'docs' level, src/hybrid.py:32-53).
+    Difference to --host_fusion: the fused run holds the best --fusion_k docs of the union (the recall reporter reads
+    200, src/metrices.py:9), and an exact tie of two DENSE scores at the depth boundary goes to the lower doc ordinal
+    instead of the lower row (include/msr.h)."""
+    import numpy as np
+
+    from .dense import DenseIndex, hybrid_search, row_to_ordinal
+    from .run import get_run_dict
+
+    ix = searcher.index
+    depth = min(a.depth, 1024)
+    k_f = max(1, min(a.fusion_k, 1024))
+    q_ptr, q_term, q_w = ix.encode_queries(texts)
+    q = np.stack([q_reps_by_id[x] for x in qids]).astype(np.float32) if qids else np.zeros((0, p_reps.shape[1]), np.float32)
+    q = q / np.maximum(np.linalg.norm(q, axis=1, keepdims=True), 1e-12)                # F.normalize, src/search.py:342
+    dix = DenseIndex(p_reps, device=ix.device)
+    try:
+        table = ix.docid_table()
+        ord_of = {d: o for o, d in enumerate(table.tolist())}
+        r2o = np.asarray([ord_of[str(x)] for x in p_lookup], dtype=np.uint32)
+        self_ord = np.asarray([ord_of.get(x, -1) for x in qids], dtype=np.int32) if a.remove_query else None
+        drop = searcher.min_idf >= 0 if searcher.drop_df_eq_n is None else bool(searcher.drop_df_eq_n)
+        ords, fs, cnt, _ = hybrid_search(ix, dix, q_ptr, q_term, q_w, q, depth, k_f, a.alpha, r2o, self_ord, drop_df_eq_n=drop)
+        fs_rows = fs.tolist()
+        fusion_run = {qid: dict(zip(table[ords[i, :cnt[i]]].tolist(), fs_rows[i][:cnt[i]])) for i, qid in enumerate(qids)}
+        sparse_run, dense_run = {}, {}
+        if not a.fusion_only:
+            o, f, _, c = ix.search_csr(q_ptr, q_term, q_w, depth, drop_df_eq_n=drop)
+            f_rows = f.tolist()
+            sparse_run = get_run_dict(qids, [f_rows[i][:c[i]] for i in range(len(qids))],
+                                      [table[o[i, :c[i]]].tolist() for i in range(len(qids))], a.remove_query)
+            d_scores, d_idx = dix.search(q, min(depth, dix.n))
+            lookup = np.asarray([str(x) for x in p_lookup], dtype=object)
+            dense_run = get_run_dict(qids, d_scores, lookup[d_idx], a.remove_query)
+    finally:
+        dix.close()
+    return sparse_run, dense_run, fusion_run
+
+
 def _cmd_eval(a):
     """Standalone recall reporter over TREC runs: sparse/dense/fusion.trec (src/hybrid.py:8-29
     format) + the dataset csv -> the reference's print-out (src/metrices.py:103-137). Default denominator: the true
@@ -233,7 +286,13 @@ def _cmd_eval(a):
     query_ids = ds.text_id_list if a.query_type == "text" else ds.img_id_list
     if a.queries:
         query_ids = read_queries(a.queries)[0]
-    look_up = sorted({d for v in dense_run.values() for d in v["docs"]})
+    # the reference prints len(look_up) = the number of corpus passages (src/metrices.py:106): take it from
+    # --n_passages, else from the dataset's passage universe, else from the docs the dense run happens to hold
+    if a.n_passages:
+        look_up = list(range(a.n_passages))
+    else:
+        universe = ds.img_id_list if a.query_type == "text" else ds.text_id_list
+        look_up = list(universe) or sorted({d for v in dense_run.values() for d in v["docs"]})
     args = SimpleNamespace(query_type=a.query_type)
     world = a.world_size if a.compat_denominator else 1
     m = replay_ranks(ds, dense_run, sparse_run, fusion_run, look_up, query_ids, args, world, compat=a.compat_denominator)
@@ -283,6 +342,11 @@ def main(argv=None):
     s.add_argument("--queries", default=None)
     s.add_argument("--qrels", default=None)
     s.add_argument("--device", type=int, default=0)
+    s.add_argument("--host_fusion", action="store_true",
+                   help="hybrid: the reference's own structure (dense + sparse lists per batch, fuse() on the host) "
+                        "instead of one msr_hybrid_search call over the whole query file")
+    s.add_argument("--fusion_k", type=int, default=1000, help="hybrid on the GPU: docs kept of each query's fused union (<= 1024)")
+    s.add_argument("--fusion_only", action="store_true", help="hybrid on the GPU: skip the separate sparse and dense runs")
     s.add_argument("--compat-denominator", "--compat_denominator", dest="compat_denominator", action="store_true",
                    help="multi-rank: keep the sampler's padded repeats and divide by len(shard) * world like the reference")
     s.set_defaults(fn=_cmd_search)
@@ -295,6 +359,8 @@ def main(argv=None):
     v.add_argument("--qrels", required=True, help="dataset csv (data/flickr/flickr_test.csv schema, src/dataset.py:86-102)")
     v.add_argument("--dataset_name", default="flickr")
     v.add_argument("--query_type", default="text")
+    v.add_argument("--n_passages", type=int, default=0, help="corpus size for the dense report's header line "
+                                                            "(default: the dataset's passage universe)")
     v.add_argument("--queries", default=None, help="query.tsv giving the query universe / order (default: the csv's)")
     v.add_argument("--compat-denominator", "--compat_denominator", dest="compat_denominator", action="store_true")
     v.add_argument("--world_size", type=int, default=4, help="ranks to replay with --compat-denominator "

@@ -1411,15 +1411,13 @@ int msr_term_str(const msr_index* ix, uint32_t term_id, const char** s) {
 // Query strings as the reference builds them (every token repeated `weight` times, src/search.py:419-422) -> CSR of
 // (term id, count): whitespace split, token-frequency count, dictionary lookup (out-of-vocabulary tokens dropped), all
 // in one pass on the host. This is the half of pyserini's batch_search that runs before Lucene.
-static void encode_query_strings(const msr_index* ix, const char* const* queries, int nq, std::vector<int64_t>& q_ptr,
-                                 std::vector<int32_t>& q_term, std::vector<int32_t>& q_w) {
-    q_ptr.assign((size_t)nq + 1, 0);
-    q_term.clear();
-    q_w.clear();
+static void encode_query_range(const msr_index* ix, const char* const* queries, int q0, int q1, int64_t* counts,
+                               std::vector<int32_t>& q_term, std::vector<int32_t>& q_w) {
     std::unordered_map<std::string, int32_t> slot;  // token -> index into q_term/q_w of the current query
     std::string tok;
-    for (int i = 0; i < nq; ++i) {
+    for (int i = q0; i < q1; ++i) {
         slot.clear();
+        const size_t first = q_term.size();
         const char* p = queries[i] ? queries[i] : "";
         // The reference writes a token `weight` times IN A ROW (src/search.py:419-422): a token equal to its
         // predecessor bumps the same slot without touching the hash map.
@@ -1456,7 +1454,54 @@ static void encode_query_strings(const msr_index* ix, const char* const* queries
             q_term.push_back(tid);
             q_w.push_back(1);
         }
-        q_ptr[(size_t)i + 1] = (int64_t)q_term.size();
+        counts[i] = (int64_t)(q_term.size() - first);
+    }
+}
+
+// Big batches (a whole query file: 5 000 strings of ~18 000 tokens each at the reference's shapes) are encoded by several
+// threads over contiguous query ranges and laid end to end: the result is the serial one.
+static void encode_query_strings(const msr_index* ix, const char* const* queries, int nq, std::vector<int64_t>& q_ptr,
+                                 std::vector<int32_t>& q_term, std::vector<int32_t>& q_w) {
+    q_ptr.assign((size_t)nq + 1, 0);
+    q_term.clear();
+    q_w.clear();
+    const int n_parts = nq >= 64 ? std::min(clamp_threads(0), std::min(16, nq / 16)) : 1;
+    if (n_parts <= 1) {
+        encode_query_range(ix, queries, 0, nq, q_ptr.data() + 1, q_term, q_w);
+    } else {
+        std::vector<std::vector<int32_t>> pt((size_t)n_parts), pw((size_t)n_parts);
+        parallel_run(n_parts, [&](int pi) {
+            const int a = (int)((int64_t)nq * pi / n_parts), b = (int)((int64_t)nq * (pi + 1) / n_parts);
+            encode_query_range(ix, queries, a, b, q_ptr.data() + 1, pt[(size_t)pi], pw[(size_t)pi]);
+        });
+        for (int pi = 0; pi < n_parts; ++pi) {
+            q_term.insert(q_term.end(), pt[(size_t)pi].begin(), pt[(size_t)pi].end());
+            q_w.insert(q_w.end(), pw[(size_t)pi].begin(), pw[(size_t)pi].end());
+        }
+    }
+    for (int i = 0; i < nq; ++i) q_ptr[(size_t)i + 1] += q_ptr[(size_t)i];  // counts -> end offsets
+}
+
+int msr_encode_queries(const msr_index* ix, const char* const* queries, int nq, int64_t* q_ptr, int32_t* q_term,
+                       int32_t* q_w, int64_t cap, int64_t* n_entries) {
+    if (!ix || nq < 0 || (nq && !queries) || !q_ptr || !n_entries || cap < 0 || (cap && (!q_term || !q_w))) {
+        set_error("msr_encode_queries: bad argument");
+        return MSR_E_INVAL;
+    }
+    try {
+        std::vector<int64_t> p;
+        std::vector<int32_t> t, w;
+        encode_query_strings(ix, queries, nq, p, t, w);
+        memcpy(q_ptr, p.data(), ((size_t)nq + 1) * sizeof(int64_t));
+        *n_entries = (int64_t)t.size();
+        if ((int64_t)t.size() <= cap && !t.empty()) {
+            memcpy(q_term, t.data(), t.size() * sizeof(int32_t));
+            memcpy(q_w, w.data(), w.size() * sizeof(int32_t));
+        }
+        return MSR_OK;
+    } catch (const std::bad_alloc&) {
+        set_error("out of host memory while encoding the queries");
+        return MSR_E_NOMEM;
     }
 }
 

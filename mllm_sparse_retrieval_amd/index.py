@@ -201,6 +201,22 @@ class SparseIndex:
         del keep
         return ords, sc, su, n
 
+    def encode_queries(self, queries):
+        """Query strings (src/search.py:419-422) -> CSR (q_ptr int64, term ids int32, counts int32), tokenised and looked
+        up in C on several threads; out-of-vocabulary tokens are dropped (contract T2)."""
+        nq = len(queries)
+        arr, keep = _cabi.c_str_array(queries)
+        q_ptr = np.zeros(nq + 1, dtype=np.int64)
+        need = C.c_int64()
+        check(lib().msr_encode_queries(self._h, C.cast(arr, C.c_void_p), nq, ptr(q_ptr), None, None, 0, C.byref(need)))
+        q_term = np.empty(need.value, dtype=np.int32)
+        q_w = np.empty(need.value, dtype=np.int32)
+        if need.value:
+            check(lib().msr_encode_queries(self._h, C.cast(arr, C.c_void_p), nq, ptr(q_ptr), ptr(q_term), ptr(q_w),
+                                           need.value, C.byref(need)))
+        del keep
+        return q_ptr, q_term, q_w
+
     def batch(self, q_ptr, q_term, q_w, kmax, drop_df_eq_n=True, term_shard=None):
         if term_shard is None:
             term_shard = self.term_shard  # a term-shard handle only takes batches of its own term range

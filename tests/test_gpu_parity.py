@@ -353,6 +353,25 @@ def test_cli_search_end_to_end(m, tmp_path, capsys):
            for name in ("Dense reps recall", "Sparse reps recall", "Fusion/Hybrid reps recall")}
     assert rec["Fusion/Hybrid reps recall"] >= max(rec["Dense reps recall"], rec["Sparse reps recall"]) - 0.02
     assert os.path.exists(tmp_path / "runs2" / "fusion.trec")
+    # that was ONE msr_hybrid_search call over the query file; --host_fusion is the reference's own structure (lists per
+    # batch + fuse() on the host, src/search.py:455-461): the same report, the same runs
+    recall_lines = [l for l in out.splitlines() if "recall" in l]
+    cli.main(["search", "--sparse_index", enc, "--passage_reps", dense, "--depth", "100", "--batch_size", "500",
+              "--alpha", "0.5", "--query_type", "text", "--dataset_name", "flickr", "--host_fusion",
+              "--qrels", os.path.join(enc, "qrels.csv"), "--save_dir", str(tmp_path / "runs3")])
+    out3 = capsys.readouterr().out
+    assert [l for l in out3.splitlines() if "recall" in l] == recall_lines
+    for name in ("sparse.trec", "dense.trec"):
+        a, b = read_trec_run(str(tmp_path / "runs2" / name)), read_trec_run(str(tmp_path / "runs3" / name))
+        assert a.keys() == b.keys()
+        assert all(list(a[q]["docs"]) == list(b[q]["docs"]) for q in a), name
+    fa, fb = read_trec_run(str(tmp_path / "runs2" / "fusion.trec")), read_trec_run(str(tmp_path / "runs3" / "fusion.trec"))
+    for q in fb:   # the GPU run keeps the best --fusion_k of the union; scores within 1e-5, order equal up to near-ties
+        da, db = fa[q]["docs"], fb[q]["docs"]
+        assert set(da) <= set(db) and len(da) == min(len(db), 1000)
+        assert max(abs(da[d] - db[d]) for d in da) <= 1e-5
+        ra, rb = list(da)[:10], list(db)[:10]
+        assert all(x == y or abs(db[x] - db[y]) <= 2e-6 for x, y in zip(ra, rb))
 
 
 def _free_port():
