@@ -528,11 +528,19 @@ def run_headline(args, ranks, m, wlmod):
             ix.search_csr(qp, qt, qw, wl.k)
             e2e = time.perf_counter() - t0
             q4 = (qp[:5] - qp[0]), qt[: qp[4]], qw[: qp[4]]
-            ix.search_csr(*q4, wl.k)
-            t0 = time.perf_counter()
-            for _ in range(50):
+            for _ in range(20):
                 ix.search_csr(*q4, wl.k)
-            small = (time.perf_counter() - t0) / 50
+            t0 = time.perf_counter()
+            for _ in range(200):
+                ix.search_csr(*q4, wl.k)
+            small = (time.perf_counter() - t0) / 200
+            laps = None   # where the microseconds of such a call go (msr_search_laps; averaged over 200 more calls)
+            for _ in range(200):
+                ix.search_csr(*q4, wl.k)
+                one = m.search_laps()
+                laps = one if laps is None else {key: laps[key] + v for key, v in one.items()}
+            laps = {key: round(v / 200, 2) for key, v in laps.items() if not key.endswith("_kernel")}
+            laps["python_and_ctypes"] = round(small * 1e6 - laps["call_total"], 2)
             # ... and the drop-in class itself on query STRINGS (tokens repeated weight times, src/search.py:419-422)
             from mllm_sparse_retrieval_amd.compat import LuceneImpactSearcher
 
@@ -547,6 +555,12 @@ def run_headline(args, ranks, m, wlmod):
             searcher.close()
             out["host_inclusive"] = {"queries_per_s_one_call": round(nq / e2e, 1),
                                      "ms_per_call_4_queries": round(small * 1e3, 4),
+                                     "us_breakdown_4_queries": laps,
+                                     "us_breakdown_note": "prepare_upload = query normalisation on the host + writing the CSR "
+                                     "into mapped pinned memory (the kernels read it over PCIe: no upload on the stream); "
+                                     "enqueue_kernels = two launches (score_tiles, merge_small); wait_stream = launch latency "
+                                     "+ both kernels + completion (two dependent EMPTY kernels + sync measure 16.0 us on this "
+                                     "box, profiles/r03_latency_lab.txt); download = copy out of the mapped result block",
                                      "queries_per_s_4_per_call": round(4 / small, 1),
                                      "ms_per_batch_search_4_query_strings": round(dropin * 1e3, 4),
                                      "tokens_per_query_string": round(sum(len(x.split()) for x in strings) / 4, 1)}
@@ -848,6 +862,21 @@ def run_c5(args, ranks, m, wlmod, shape="t2i"):
             bound = max(cands, key=cands.get) if cands else None
             rl[stage] = {"bound": bound, "frac": cands.get(bound) if bound else None, "kernel_ms": round(ms[key], 4), **fr}
     out["roofline"] = rl
+    if not args.no_cpu and shape == "i2t":
+        # the dense search alone at the batch sizes the reference runs it with (PCIe-inclusive: host f32 queries in, host
+        # lists out): --batch_size 2 (scripts/search.sh:29) and the default 128 (src/arguments.py:60)
+        rows = {}
+        for bs in (2, 128):
+            dix.search(q[:bs], depth)
+            a0 = dix.stats()["device_allocs"]
+            t0 = time.perf_counter()
+            for _ in range(20):
+                dix.search(q[:bs], depth)
+            dt = (time.perf_counter() - t0) / 20
+            rows[f"batch_{bs}"] = {"ms_per_call": round(dt * 1e3, 4), "queries_per_s": round(bs / dt, 1),
+                                   "kernel_ms": {"gemm": round(dix.last_ms[0], 4), "select": round(dix.last_ms[1], 4)},
+                                   "device_allocs_in_20_calls": dix.stats()["device_allocs"] - a0}
+        out["host_inclusive_dense_search"] = rows
     if not args.no_cpu:
         phase(f"{wname} parity sample vs the oracle pipeline")
         out["parity"] = c5_parity_sample(m, docs, n_terms, qp, qt, qw, p, q, depth, k, alpha,

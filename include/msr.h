@@ -127,6 +127,12 @@ int msr_search_csr(msr_index* ix, const int64_t* q_ptr, const int32_t* q_term, c
                    uint32_t flags, uint32_t* out_doc_ord, float* out_score, uint32_t* out_score_u32,
                    int32_t* out_n);
 
+/* Where the calling thread's last msr_search_csr spent its time, in microseconds: {query normalisation + device buffers
+ * + upload enqueued, kernels enqueued, wait for the stream, download + copy out, release, the whole call, HIP-event span
+ * of the scoring kernel(s), of the merge}. The reference calls batch_search with 4 queries at a time
+ * (scripts/search_sparse.sh:16): such a call is launch- and copy-latency, not kernel time. */
+int msr_search_laps(double out_us[8]);
+
 /* The same search for query STRINGS as the reference builds them (each token repeated `weight` times,
  * src/search.py:419-422): whitespace split, token counts and dictionary lookup happen on the host inside this call —
  * the work pyserini's batch_search does in Python before handing the query to Lucene. */
@@ -213,6 +219,10 @@ int msr_dense_open(const uint16_t* p_fp16, uint64_t n, uint32_t h, int device, m
 int msr_dense_search(msr_dense* dx, const uint16_t* q_fp16, int nq, int k, uint32_t* out_idx, uint32_t* out_key,
                      int32_t* out_n, float* gemm_ms, float* select_ms);
 void msr_dense_close(msr_dense* dx);
+/* Bookkeeping of a dense handle: out = {hipMalloc calls made for its scratch so far, scratch bytes it holds, rows, dim}.
+ * The scratch of msr_dense_search / msr_hybrid_search stays with the handle and is only ever grown, so repeated calls of
+ * one shape allocate nothing (the reference searches in batches of 2, scripts/search.sh:29). */
+int msr_dense_stats(const msr_dense* dx, uint64_t out[4]);
 /* Host helper for the two calls above: n f32 values -> IEEE fp16, round to nearest even (what numpy's astype(float16)
  * and the reference's .half() produce: src/search.py:257), on `threads` host threads (<= 0: all). The reference hands
  * its query matrix over in f32 (src/search.py:342-343); converting 25 010 x 4 096 values in numpy takes longer than

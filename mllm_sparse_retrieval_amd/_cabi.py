@@ -58,6 +58,7 @@ SYMBOLS = [
     ("msr_term_str", _I, [_VP, _U32, C.POINTER(_CP)]),
     ("msr_docid_str", _I, [_VP, _U32, C.POINTER(_CP)]),
     ("msr_search_csr", _I, [_VP, _VP, _VP, _VP, _I, _I, _U32, _VP, _VP, _VP, _VP]),
+    ("msr_search_laps", _I, [_VP]),
     ("msr_search_text", _I, [_VP, _VP, _I, _I, _U32, _VP, _VP, _VP, _VP]),
     ("msr_encode_queries", _I, [_VP, _VP, _I, _VP, _VP, _VP, C.c_int64, C.POINTER(C.c_int64)]),
     ("msr_batch_create", _I, [_VP, _VP, _VP, _VP, _I, _I, _U32, C.POINTER(_VP)]),
@@ -86,6 +87,7 @@ SYMBOLS = [
     ("msr_dense_open", _I, [_VP, _U64, _U32, _I, C.POINTER(_VP)]),
     ("msr_dense_search", _I, [_VP, _VP, _I, _I, _VP, _VP, _VP, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
     ("msr_dense_close", None, [_VP]),
+    ("msr_dense_stats", _I, [_VP, _VP]),
     ("msr_f32_to_f16", _I, [_VP, _VP, _U64, _I]),
     ("msr_hybrid_search", _I, [_VP, _VP, _VP, _VP, _VP, _VP, _I, _I, _I, C.c_float, _U32, _VP, _VP, _VP, _VP, _VP, _VP]),
     ("msr_sparsify", _I, [_VP, _I, _I, _I, _U32, _I, _I, _VP, _VP, _VP]),

@@ -8,6 +8,8 @@
 //     ties broken by external doc id ascending (= lower ordinal).
 #include <dlfcn.h>
 
+#include <chrono>
+
 #include "msr_kernels.hpp"
 
 namespace msr {
@@ -124,6 +126,12 @@ int device_attach(msr_index* ix, int device) {
     if (hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking) != hipSuccess) {
         set_error("hipStreamCreate failed");
         return fail(MSR_E_HIP);
+    }
+    // (optional: without it every call takes the ordinary path)
+    if (hipHostMalloc(&d->h_zc, 2 * kZeroCopyBytes, hipHostMallocMapped) == hipSuccess) {
+        if (hipHostGetDevicePointer(&d->d_zc, d->h_zc, 0) != hipSuccess) d->d_zc = nullptr;
+    } else {
+        d->h_zc = nullptr;
     }
     const uint64_t stride = (uint64_t)h->n_terms + 1;
     const uint32_t t0 = ix->shard_tile0, nt = ix->shard_ntiles;
@@ -270,6 +278,7 @@ void device_detach(msr_index* ix) {
     for (hipEvent_t e : d->spare_events) (void)hipEventDestroy(e);
     if (d->stage_ev) (void)hipEventDestroy(d->stage_ev);
     if (d->h_stage) (void)hipHostFree(d->h_stage);
+    if (d->h_zc) (void)hipHostFree(d->h_zc);
     if (d->d_seg_ptr) (void)hipFree(d->d_seg_ptr);
     if (d->d_postings) (void)hipFree(d->d_postings);
     if (d->d_dense) (void)hipFree(d->d_dense);
@@ -382,8 +391,10 @@ extern "C" {
 
 }  // extern "C"
 
+// small = msr_search_csr's own batch: no HIP events, and — when the result block fits — results written straight to
+// mapped host memory
 static int batch_create_impl(msr_index* ix, const int64_t* q_ptr, const int32_t* q_term, const int32_t* q_w, int nq,
-                             int kmax, uint32_t flags, int shard, int n_shards, msr_batch** out) {
+                             int kmax, uint32_t flags, int shard, int n_shards, msr_batch** out, bool small = false) {
     if (!out) {
         set_error("msr_batch_create: null output");
         return MSR_E_INVAL;
@@ -575,8 +586,12 @@ static int batch_create_impl(msr_index* ix, const int64_t* q_ptr, const int32_t*
         if (p) b->pooled.emplace_back(p, bytes);
         return p;
     };
-    uint32_t* d_in = (uint32_t*)take(std::max<size_t>(in_words, 1) * 4);
-    uint32_t* d_out = (uint32_t*)take(std::max<size_t>(out_words, 1) * 4);
+    // small call: queries and results live in the handle's mapped host block (first half in, second half out)
+    b->untimed = small;
+    b->zero_copy = small && d->d_zc && in_words * 4 <= kZeroCopyBytes && out_words * 4 <= kZeroCopyBytes &&
+                   ntiles * (size_t)std::max(nq, 1) <= kSmallMaxPairs && n_shards == 0;
+    uint32_t* d_in = b->zero_copy ? (uint32_t*)d->d_zc : (uint32_t*)take(std::max<size_t>(in_words, 1) * 4);
+    uint32_t* d_out = b->zero_copy ? (uint32_t*)d->d_zc + kZeroCopyBytes / 4 : (uint32_t*)take(std::max<size_t>(out_words, 1) * 4);
     b->d_part = (uint64_t*)take(ntiles * nqk * 8);
     b->d_keys = (uint64_t*)take(nqk * 8);
     if (!d_in || !d_out || !b->d_part || !b->d_keys) {
@@ -591,7 +606,17 @@ static int batch_create_impl(msr_index* ix, const int64_t* q_ptr, const int32_t*
     b->d_su32 = d_out + o_su;
     b->d_sf32 = reinterpret_cast<float*>(d_out + o_sf);
     b->d_n = reinterpret_cast<int32_t*>(d_out + o_n);
-    {
+    if (b->zero_copy) {
+        // the kernels read the few hundred bytes of a small batch over PCIe themselves: no staging copy, no upload on
+        // the stream (an upload costs the stream ~3.5 us, three dependent reads from host memory ~2.6: scripts/latency_lab.hip)
+        uint32_t* hs = (uint32_t*)d->h_zc;
+        memcpy(hs + o_ptr, qptr.data(), qptr.size() * 4);
+        if (!qterm.empty()) {
+            memcpy(hs + o_term, qterm.data(), qterm.size() * 4);
+            memcpy(hs + o_w, qw.data(), qw.size() * 4);
+        }
+        if (!qdense.empty()) memcpy(hs + o_dense, qdense.data(), qdense.size() * 4);
+    } else {
         const size_t in_bytes = in_words * 4;
         bool ok = true;
         if (in_bytes <= (8u << 20)) {
@@ -661,7 +686,7 @@ int batch_search_local(msr_batch* b, int k, bool final_arrays) {
     HIP_TRY(hipSetDevice(d->device));
     // every call gets its own event triple so that a whole timed region can be summed afterwards
     if (b->calls >= 4096) b->calls = 0;  // bounded: callers that never reset keep only the recent calls
-    while (b->events.size() < (b->calls + 1) * 3) {
+    while (!b->untimed && b->events.size() < (b->calls + 1) * 3) {
         hipEvent_t e = nullptr;
         if (!d->spare_events.empty()) {
             e = d->spare_events.back();
@@ -671,11 +696,13 @@ int batch_search_local(msr_batch* b, int k, bool final_arrays) {
         }
         b->events.push_back(e);
     }
-    b->ev0 = b->events[b->calls * 3 + 0];
-    b->ev1 = b->events[b->calls * 3 + 1];
-    b->ev2 = b->events[b->calls * 3 + 2];
-    b->calls++;
-    HIP_TRY(hipEventRecord(b->ev0, d->stream));
+    if (!b->untimed) {
+        b->ev0 = b->events[b->calls * 3 + 0];
+        b->ev1 = b->events[b->calls * 3 + 1];
+        b->ev2 = b->events[b->calls * 3 + 2];
+        b->calls++;
+        HIP_TRY(hipEventRecord(b->ev0, d->stream));
+    }
     ScoreArgs sa;
     sa.seg_ptr = d->d_seg_ptr;
     sa.postings = d->d_postings;
@@ -750,7 +777,7 @@ int batch_search_local(msr_batch* b, int k, bool final_arrays) {
         rc = launch_score(d->stream, h->tile_docs, t1, nt, sa);
         if (rc != MSR_OK) return rc;
     }
-    HIP_TRY(hipEventRecord(b->ev1, d->stream));
+    if (!b->untimed) HIP_TRY(hipEventRecord(b->ev1, d->stream));
     MergeArgs ma;
     ma.lists = b->d_part;
     ma.list_stride = (uint64_t)b->nq * k;
@@ -764,9 +791,9 @@ int batch_search_local(msr_batch* b, int k, bool final_arrays) {
     ma.out_n = b->d_n;
     rc = launch_merge(d->stream, ma);
     if (rc != MSR_OK) return rc;
-    HIP_TRY(hipEventRecord(b->ev2, d->stream));
+    if (!b->untimed) HIP_TRY(hipEventRecord(b->ev2, d->stream));
     b->last_k = k;
-    b->timed = true;
+    b->timed = !b->untimed;
     return MSR_OK;
 }
 
@@ -799,6 +826,14 @@ int msr_batch_fetch(msr_batch* b, uint32_t* out_doc_ord, float* out_score, uint3
     int rc = msr_batch_sync(b);
     if (rc != MSR_OK) return rc;
     const size_t n = (size_t)b->nq * b->last_k;
+    if (b->zero_copy) {  // the kernels wrote into mapped host memory: nothing to download
+        const uint32_t* hs = (const uint32_t*)b->ix->dev->h_zc + kZeroCopyBytes / 4;
+        if (n && out_doc_ord) memcpy(out_doc_ord, hs, n * 4);
+        if (n && out_score_u32) memcpy(out_score_u32, hs + (b->d_su32 - b->d_ord), n * 4);
+        if (n && out_score) memcpy(out_score, hs + ((const uint32_t*)b->d_sf32 - b->d_ord), n * 4);
+        if (out_n && b->nq) memcpy(out_n, hs + ((const uint32_t*)b->d_n - b->d_ord), (size_t)b->nq * 4);
+        return MSR_OK;
+    }
     {
         // small results: the whole output block in one copy through the pinned staging buffer
         DeviceIndex* d = b->ix->dev;
@@ -890,15 +925,47 @@ int msr_batch_algo_bytes(const msr_batch* b, int k, uint64_t* bytes, uint64_t* p
 
 void msr_batch_destroy(msr_batch* b) { batch_free(b); }
 
+// host-side laps of the calling thread's last msr_search_csr (msr_search_laps): where a small call's time goes
+static thread_local double g_laps[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+
 int msr_search_csr(msr_index* ix, const int64_t* q_ptr, const int32_t* q_term, const int32_t* q_w, int nq, int k,
                    uint32_t flags, uint32_t* out_doc_ord, float* out_score, uint32_t* out_score_u32, int32_t* out_n) {
+    using clk = std::chrono::steady_clock;
+    auto us = [](clk::time_point a, clk::time_point b) { return std::chrono::duration<double, std::micro>(b - a).count(); };
+    const auto t0 = clk::now();
     msr_batch* b = nullptr;
-    int rc = msr_batch_create(ix, q_ptr, q_term, q_w, nq, k, flags, &b);
+    static const bool timed_calls = getenv("MSR_TIME_SEARCH_CALLS") != nullptr;  // diagnostic: HIP events around the kernels
+    int rc = batch_create_impl(ix, q_ptr, q_term, q_w, nq, k, flags, 0, 0, &b, !timed_calls);
     if (rc != MSR_OK) return rc;
+    const auto t1 = clk::now();
     rc = msr_batch_search(b, k);
+    const auto t2 = clk::now();
+    if (rc == MSR_OK) rc = msr_batch_sync(b);
+    const auto t3 = clk::now();
     if (rc == MSR_OK) rc = msr_batch_fetch(b, out_doc_ord, out_score, out_score_u32, out_n);
+    const auto t4 = clk::now();
+    float score_ms = 0, merge_ms = 0;
+    if (rc == MSR_OK && b->timed) (void)msr_batch_kernel_ms(b, &score_ms, &merge_ms);
     msr_batch_destroy(b);
+    const auto t5 = clk::now();
+    g_laps[0] = us(t0, t1);  // query normalisation + pooled buffers + staging + upload enqueued
+    g_laps[1] = us(t1, t2);  // kernels enqueued
+    g_laps[2] = us(t2, t3);  // wait for the stream: upload + kernels (+ launch latency)
+    g_laps[3] = us(t3, t4);  // download through pinned staging + copy out
+    g_laps[4] = us(t4, t5);  // events read, buffers back to the pool
+    g_laps[5] = us(t0, t5);  // the whole call
+    g_laps[6] = 1e3 * score_ms;  // HIP-event spans on the stream: scoring kernel(s) ...
+    g_laps[7] = 1e3 * merge_ms;  // ... and the merge
     return rc;
+}
+
+int msr_search_laps(double out_us[8]) {
+    if (!out_us) {
+        set_error("msr_search_laps: null output");
+        return MSR_E_INVAL;
+    }
+    memcpy(out_us, g_laps, sizeof(g_laps));
+    return MSR_OK;
 }
 
 // ------------------------------------------------------------------------------------------------ merge of host lists

@@ -30,6 +30,8 @@ constexpr int kCandCap = 1024;   // candidate keys per workgroup (>= MSR_KMAX)
 constexpr uint32_t kMaxGridY = 65535;  // HIP grid limit in y (tiles per launch)
 constexpr uint64_t kMinStagedPairs = 4096;  // ... and only launches with at least this many (tile, query) pairs are staged
 constexpr uint32_t kStage1Fraction = 16;  // staged search: 1/16 of the tiles (at least one) set the thresholds
+constexpr size_t kZeroCopyBytes = 64u << 10;  // query block / result block of a small call (mapped host memory)
+constexpr uint32_t kSmallMaxPairs = 1024;     // a small call launches at most this many (tile, query) workgroups
 constexpr int kChunkVecs = 64;   // one chunk = one wave-wide uint4 load = 256 postings = 1 KiB
 static_assert(kCandCap >= MSR_KMAX, "candidate buffer must hold k keys");
 
@@ -84,6 +86,10 @@ struct DeviceIndex {
     size_t h_stage_bytes = 0;
     hipEvent_t stage_ev = nullptr;         // recorded after an async upload out of h_stage ...
     bool stage_pending = false;            // ... and waited for before the buffer is written or freed again
+    // small calls (the reference's 4 queries per batch_search): the kernels read the queries from, and write the results
+    // to, mapped pinned host memory — no upload and no download on the stream (each costs it ~3.5 us, scripts/latency_lab.hip)
+    void* h_zc = nullptr;                  // hipHostMalloc(mapped), 2 x kZeroCopyBytes: queries | results
+    void* d_zc = nullptr;                  // its device view
     uint32_t* d_seg_ptr = nullptr;   // [shard_ntiles][n_terms+1] absolute vec index
     uint32_t* d_postings = nullptr;  // the shard's vecs; vec v of the index lives at d_postings + (v - vec_base)*4
     uint32_t* d_dense = nullptr;     // [shard_ntiles][n_pairs][tile_docs] dense head of the shard's tiles
@@ -168,6 +174,8 @@ int launch_merge(hipStream_t st, const MergeArgs& a);
 struct msr_batch {
     msr_index* ix = nullptr;
     bool unsorted_ok = false;  // hybrid path: the consumer of d_keys treats each query's list as a set
+    bool zero_copy = false;    // small call: d_qptr .. d_qdense and d_ord .. d_n are device views of the handle's mapped host block
+    bool untimed = false;      // no HIP events around the kernels (msr_search_csr's own batches)
     int nq = 0;
     int kmax = 0;
     int last_k = 0;

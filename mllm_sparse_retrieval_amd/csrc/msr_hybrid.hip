@@ -383,9 +383,11 @@ struct msr_dense {
     bool lds_attr_set = false;  // dense_scores_256 needs the 128 KiB dynamic-LDS opt-in once per device
     // device scratch of the fused hybrid call (query matrix, score rows, result lists), kept between calls and only ever
     // grown: six hipMalloc / hipFree pairs of up to 200 MB cost a call more than its kernels
-    void* scratch[12] = {};
-    size_t scratch_bytes[12] = {};
+    enum Slot { S_Q = 0, S_S, S_ORD, S_SF, S_N, S_SELF, S_CS, S_CD, S_META, S_FLAGS, S_QLIST, S_PART, S_SU, S_COUNT };
+    void* scratch[S_COUNT] = {};
+    size_t scratch_bytes[S_COUNT] = {};
     uint64_t n_device_allocs = 0;  // hipMalloc calls made on behalf of this handle (steady-state calls make none)
+    hipEvent_t ev[3] = {nullptr, nullptr, nullptr};  // msr_dense_search's laps, created on first use
     void* take(int slot, size_t bytes) {
         if (scratch_bytes[slot] >= bytes && scratch[slot]) return scratch[slot];
         if (scratch[slot]) (void)hipFree(scratch[slot]);
@@ -451,8 +453,24 @@ void msr_dense_close(msr_dense* dx) {
     if (dx->d_P) (void)hipFree(dx->d_P);
     for (void* p : dx->scratch)
         if (p) (void)hipFree(p);
+    for (hipEvent_t e : dx->ev)
+        if (e) (void)hipEventDestroy(e);
     if (dx->stream) (void)hipStreamDestroy(dx->stream);
     delete dx;
+}
+
+// Row blocks (of 256 queries) per GEMM launch: among the chunk sizes that fit (<= rb_max, <= the batch), the one whose
+// grid of row blocks x col_blocks fills its last round of the chip's 256 CUs best (2 x 98 blocks leave a quarter of the
+// chip idle, 5 x 98 = 490 fill 1.91 rounds); ties go to the larger chunk.
+static uint32_t pick_row_blocks(uint32_t col_blocks, uint64_t rb_max, uint32_t batch_row_blocks) {
+    uint32_t best = 1;
+    double best_eff = 0;
+    for (uint64_t rb = 1; rb <= std::min<uint64_t>(rb_max, std::max<uint32_t>(batch_row_blocks, 1)); ++rb) {
+        const uint64_t blocks = rb * std::max<uint32_t>(col_blocks, 1);
+        const double eff = (double)blocks / (double)((blocks + 255) / 256 * 256);
+        if (eff >= best_eff - 1e-9) best_eff = eff, best = (uint32_t)rb;
+    }
+    return best;
 }
 
 // C = Q * P^T as order-preserving keys into out[q][ld] for doc columns [0, n_cover); rows of Q padded to qn_pad (a
@@ -513,27 +531,29 @@ static int dense_search_impl(msr_dense* dx, const uint16_t* q_fp16, int nq, int 
         return MSR_E_RANGE;
     }
     HIP_TRY(hipSetDevice(dx->device));
-    // queries per pass: the score buffer holds qt x n_pad u32 keys and is capped at 4 GiB (1 GiB at 8192 padded docs)
-    const uint32_t QT = (uint32_t)std::min<uint64_t>(32768, std::max<uint64_t>(256, ((1ull << 30) / std::max<uint64_t>(dx->n_pad, 1)) / 256 * 256));
-    const uint32_t qt = (uint32_t)std::min<uint32_t>(QT, std::max(nq, 1));
-    const uint32_t qt_pad = (qt + 255) / 256 * 256;
-    _Float16* d_Q = nullptr;
-    uint32_t* d_S = nullptr;
-    uint64_t *d_part = nullptr;
-    uint32_t *d_ord = nullptr, *d_su = nullptr;
-    float* d_sf = nullptr;
-    int32_t* d_n = nullptr;
-    hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr;
+    // queries per pass: score rows of at most ~256 MB (they are read back by select_tiles out of the Infinity Cache, and
+    // the buffer stays with the handle), the GEMM grid filling its last round of 256 CUs as well as it can
+    const uint32_t nq_pad_all = (uint32_t)((std::max(nq, 1) + 255) / 256 * 256);
+    const uint64_t rb_max = std::max<uint64_t>(1, (256ull << 20) / (std::max<uint64_t>(dx->n_pad, 256) * 4 * 256));
+    const uint32_t qt_pad = 256u * pick_row_blocks((uint32_t)(std::max<uint64_t>(dx->n_pad, 256) / 256), rb_max, nq_pad_all / 256);
+    const uint32_t qt = (uint32_t)std::min<uint32_t>(qt_pad, std::max(nq, 1));
     int rc = MSR_OK;
     const size_t perq = std::max<size_t>((size_t)qt * k, 1);
-    bool ok = hipMalloc(&d_Q, (size_t)qt_pad * dx->h * 2) == hipSuccess &&
-              hipMalloc(&d_S, (size_t)qt_pad * dx->n_pad * 4) == hipSuccess &&
-              hipMalloc(&d_part, (size_t)dx->n_tiles * perq * 8) == hipSuccess && hipMalloc(&d_ord, perq * 4) == hipSuccess &&
-              hipMalloc(&d_su, perq * 4) == hipSuccess && hipMalloc(&d_sf, perq * 4) == hipSuccess &&
-              hipMalloc(&d_n, (size_t)qt * 4) == hipSuccess && hipEventCreate(&e0) == hipSuccess &&
-              hipEventCreate(&e1) == hipSuccess && hipEventCreate(&e2) == hipSuccess;
+    // device scratch and events live on the handle (only ever grown): at the reference's --batch_size 2
+    // (scripts/search.sh:29) seven hipMalloc / hipFree pairs per call cost more than the search
+    _Float16* d_Q = (_Float16*)dx->take(msr_dense::S_Q, (size_t)qt_pad * dx->h * 2);
+    uint32_t* d_S = (uint32_t*)dx->take(msr_dense::S_S, (size_t)qt_pad * dx->n_pad * 4);
+    uint64_t* d_part = (uint64_t*)dx->take(msr_dense::S_PART, (size_t)dx->n_tiles * perq * 8);
+    uint32_t* d_ord = (uint32_t*)dx->take(msr_dense::S_ORD, perq * 4);
+    uint32_t* d_su = (uint32_t*)dx->take(msr_dense::S_SU, perq * 4);
+    float* d_sf = (float*)dx->take(msr_dense::S_SF, perq * 4);
+    int32_t* d_n = (int32_t*)dx->take(msr_dense::S_N, (size_t)qt * 4);
+    bool ok = d_Q && d_S && d_part && d_ord && d_su && d_sf && d_n;
+    for (hipEvent_t& e : dx->ev)
+        if (ok && !e) ok = hipEventCreate(&e) == hipSuccess;
+    hipEvent_t e0 = dx->ev[0], e1 = dx->ev[1], e2 = dx->ev[2];
     if (!ok) {
-        set_error("hipMalloc failed in msr_dense_search (%u queries per pass x %llu docs)", qt, (unsigned long long)dx->n_pad);
+        set_error("device allocation failed in msr_dense_search (%u queries per pass x %llu docs)", qt, (unsigned long long)dx->n_pad);
         rc = MSR_E_NOMEM;
     }
     double t_gemm = 0, t_sel = 0;
@@ -603,13 +623,21 @@ static int dense_search_impl(msr_dense* dx, const uint16_t* q_fp16, int nq, int 
     }
     if (gemm_ms) *gemm_ms = (float)t_gemm;
     if (select_ms) *select_ms = (float)t_sel;
-    void* ptrs[] = {d_Q, d_S, d_part, d_ord, d_su, d_sf, d_n};
-    for (void* p : ptrs)
-        if (p) (void)hipFree(p);
-    if (e0) (void)hipEventDestroy(e0);
-    if (e1) (void)hipEventDestroy(e1);
-    if (e2) (void)hipEventDestroy(e2);
     return rc;
+}
+
+int msr_dense_stats(const msr_dense* dx, uint64_t out[4]) {
+    if (!dx || !out) {
+        set_error("msr_dense_stats: bad argument");
+        return MSR_E_INVAL;
+    }
+    uint64_t bytes = 0;
+    for (size_t b : dx->scratch_bytes) bytes += b;
+    out[0] = dx->n_device_allocs;
+    out[1] = bytes;
+    out[2] = dx->n;
+    out[3] = dx->h;
+    return MSR_OK;
 }
 
 int msr_dense_search(msr_dense* dx, const uint16_t* q_fp16, int nq, int k, uint32_t* out_idx, uint32_t* out_key,
@@ -1684,14 +1712,14 @@ static int hybrid_search_fused(msr_index* ix, msr_dense* dx, const int64_t* q_pt
     if (getenv("MSR_DEBUG_HYBRID") && hipMalloc(&d_stamps, 8 * sizeof(unsigned long long)) == hipSuccess)
         (void)hipMemsetAsync(d_stamps, 0, 8 * sizeof(unsigned long long), d->stream);
     const size_t perk = std::max<size_t>((size_t)nq * k, 1);
-    d_Q = (_Float16*)dx->take(0, std::max<size_t>((size_t)nq_pad * dx->h * 2, 16));
-    d_S = (uint32_t*)dx->take(1, (size_t)qc * ld * 4);
-    d_ord = (uint32_t*)dx->take(2, perk * 4);
-    d_sf = (float*)dx->take(3, perk * 4);
-    d_n = (int32_t*)dx->take(4, std::max<size_t>(nq, 1) * 4);
+    d_Q = (_Float16*)dx->take(msr_dense::S_Q, std::max<size_t>((size_t)nq_pad * dx->h * 2, 16));
+    d_S = (uint32_t*)dx->take(msr_dense::S_S, (size_t)qc * ld * 4);
+    d_ord = (uint32_t*)dx->take(msr_dense::S_ORD, perk * 4);
+    d_sf = (float*)dx->take(msr_dense::S_SF, perk * 4);
+    d_n = (int32_t*)dx->take(msr_dense::S_N, std::max<size_t>(nq, 1) * 4);
     bool ok = d_Q && d_S && d_ord && d_sf && d_n;
     if (ok && self_ord)
-        ok = (d_self = (int32_t*)dx->take(5, std::max<size_t>(nq, 1) * 4)) != nullptr &&
+        ok = (d_self = (int32_t*)dx->take(msr_dense::S_SELF, std::max<size_t>(nq, 1) * 4)) != nullptr &&
              hipMemcpyAsync(d_self, self_ord, (size_t)nq * 4, hipMemcpyHostToDevice, d->stream) == hipSuccess;
     if (ok && nq)
         ok = hipMemsetAsync(d_Q + (size_t)nq * dx->h, 0, (size_t)(nq_pad - nq) * dx->h * 2, d->stream) == hipSuccess &&
@@ -1868,13 +1896,7 @@ static int hybrid_search_multitile(msr_index* ix, msr_dense* dx, const int64_t* 
     // that fit, the one whose GEMM grid fills its last round of 256 CUs best: 2 x 98 blocks leave a quarter of the chip
     // idle, 5 x 98 = 490 fill 1.91 rounds
     const uint64_t rb_max = std::max<uint64_t>(1, (std::max<uint64_t>(chunk_mb, 1) << 20) / (std::max<uint64_t>(n_cover, 256) * 4 * 256));
-    uint64_t row_blocks = 1;
-    double best_eff = 0;
-    for (uint64_t rb = 1; rb <= std::min<uint64_t>(rb_max, nq_pad / 256); ++rb) {
-        const uint64_t blocks = rb * std::max<uint32_t>(col_blocks, 1);
-        const double eff = (double)blocks / (double)((blocks + 255) / 256 * 256);
-        if (eff >= best_eff - 1e-9) best_eff = eff, row_blocks = rb;
-    }
+    const uint64_t row_blocks = pick_row_blocks(col_blocks, rb_max, nq_pad / 256);
     const uint32_t qc = (uint32_t)std::min<uint64_t>(row_blocks * 256, std::max<uint32_t>(nq_pad, 256u));
     const uint64_t last_docs = n - (uint64_t)(n_tiles - 1) * tile;
     const uint32_t quota_full = n_tiles > 1 ? tile_quota(tile, n, (uint32_t)depth) : tile_quota(n, n, (uint32_t)depth);
@@ -1883,20 +1905,20 @@ static int hybrid_search_multitile(msr_index* ix, msr_dense* dx, const int64_t* 
     const size_t per_tile_row = (size_t)n_tiles;
     const size_t cand_slots = std::max<size_t>((size_t)qc * per_tile_row * quota_full, per_tile_row * (size_t)depth);
     const size_t perk = std::max<size_t>((size_t)nq * k, 1);
-    _Float16* d_Q = (_Float16*)dx->take(0, std::max<size_t>((size_t)nq_pad * dx->h * 2, 16));
-    uint32_t* d_S = (uint32_t*)dx->take(1, (size_t)qc * ld * 4);
-    uint32_t* d_ord = (uint32_t*)dx->take(2, perk * 4);
-    float* d_sf = (float*)dx->take(3, perk * 4);
-    int32_t* d_n = (int32_t*)dx->take(4, std::max<size_t>(nq, 1) * 4);
-    uint64_t* d_cs = (uint64_t*)dx->take(6, cand_slots * 8);
-    uint64_t* d_cd = (uint64_t*)dx->take(7, cand_slots * 8);
-    uint4* d_meta = (uint4*)dx->take(8, std::max<size_t>((size_t)qc * per_tile_row * 2 * 16, 32));
-    uint32_t* d_flags = (uint32_t*)dx->take(9, std::max<size_t>(nq, 1) * 4);
-    uint32_t* d_qlist = (uint32_t*)dx->take(10, std::max<size_t>(nq, 1) * 4);
+    _Float16* d_Q = (_Float16*)dx->take(msr_dense::S_Q, std::max<size_t>((size_t)nq_pad * dx->h * 2, 16));
+    uint32_t* d_S = (uint32_t*)dx->take(msr_dense::S_S, (size_t)qc * ld * 4);
+    uint32_t* d_ord = (uint32_t*)dx->take(msr_dense::S_ORD, perk * 4);
+    float* d_sf = (float*)dx->take(msr_dense::S_SF, perk * 4);
+    int32_t* d_n = (int32_t*)dx->take(msr_dense::S_N, std::max<size_t>(nq, 1) * 4);
+    uint64_t* d_cs = (uint64_t*)dx->take(msr_dense::S_CS, cand_slots * 8);
+    uint64_t* d_cd = (uint64_t*)dx->take(msr_dense::S_CD, cand_slots * 8);
+    uint4* d_meta = (uint4*)dx->take(msr_dense::S_META, std::max<size_t>((size_t)qc * per_tile_row * 2 * 16, 32));
+    uint32_t* d_flags = (uint32_t*)dx->take(msr_dense::S_FLAGS, std::max<size_t>(nq, 1) * 4);
+    uint32_t* d_qlist = (uint32_t*)dx->take(msr_dense::S_QLIST, std::max<size_t>(nq, 1) * 4);
     int32_t* d_self = nullptr;
     bool ok = d_Q && d_S && d_ord && d_sf && d_n && d_cs && d_cd && d_meta && d_flags && d_qlist;
     if (ok && self_ord)
-        ok = (d_self = (int32_t*)dx->take(5, std::max<size_t>(nq, 1) * 4)) != nullptr &&
+        ok = (d_self = (int32_t*)dx->take(msr_dense::S_SELF, std::max<size_t>(nq, 1) * 4)) != nullptr &&
              hipMemcpyAsync(d_self, self_ord, (size_t)nq * 4, hipMemcpyHostToDevice, d->stream) == hipSuccess;
     if (ok && nq)
         ok = hipMemsetAsync(d_Q + (size_t)nq * dx->h, 0, (size_t)(nq_pad - nq) * dx->h * 2, d->stream) == hipSuccess &&

@@ -23,6 +23,42 @@
 
 namespace msr {
 
+// At most 64 keys per query (e.g. 4 tiles x top-10): one WAVE ranks them, keys in registers, ranks by v_readlane
+// broadcasts — no LDS, no barrier. (merge_small's body.)
+__device__ __forceinline__ void merge_wave(const MergeArgs& a, const uint32_t q, const uint32_t lane) {
+    const uint32_t n_items = a.n_lists * a.k;  // <= 64
+    uint64_t me = 0;
+    if (lane < n_items) {
+        const uint32_t l = lane / a.k, j = lane - l * a.k;
+        me = a.lists[(uint64_t)l * a.list_stride + (uint64_t)q * a.k + j];
+    }
+    const uint32_t lo = (uint32_t)me, hi = (uint32_t)(me >> 32);
+    uint32_t rank = 0;
+    for (uint32_t j = 0; j < n_items; j += 4) {  // lanes past n_items hold key 0, which outranks nobody
+#pragma unroll
+        for (uint32_t u = 0; u < 4; ++u) {
+            const uint64_t o = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)hi, (int)(j + u)) << 32) |
+                               (uint32_t)__builtin_amdgcn_readlane((int)lo, (int)(j + u));
+            rank += o > me;
+        }
+    }
+    const uint32_t n_hit = min((uint32_t)__popcll(__ballot(me != 0)), a.k);
+    // keys are unique, so the non-empty keys take ranks 0 .. n-1; slots [n_hit, k) are empty
+    const uint64_t o = (uint64_t)q * a.k;
+    auto emit = [&](uint32_t i, uint64_t key) {
+        if (a.out_keys) a.out_keys[o + i] = key;
+        if (a.out_ord) {
+            const uint32_t sc = (uint32_t)(key >> 32);
+            a.out_ord[o + i] = key ? 0xFFFFFFFFu - (uint32_t)key : 0xFFFFFFFFu;
+            a.out_score_u32[o + i] = sc;
+            a.out_score[o + i] = (float)sc;  // round-to-nearest-even, exact below 2^24 (contract T5)
+        }
+    };
+    if (me != 0 && rank < a.k) emit(rank, me);
+    if (lane >= n_hit && lane < a.k) emit(lane, 0ull);
+    if (lane == 0 && a.out_n) a.out_n[q] = (int32_t)n_hit;
+}
+
 // ------------------------------------------------------------------------------------------------ kernel 1
 // <docs per tile, threads, 1-KiB chunk loads per register bank, min waves per SIMD, candidate-key capacity (>= k), diag>
 // LIGHT: the batch's queries hold at most 64 sparse terms each -> accumulate_tile_light (msr_accumulate.hpp)
@@ -144,43 +180,12 @@ __global__ __launch_bounds__(NT) void select_tiles(const SelectArgs a) {
 // ------------------------------------------------------------------------------------------------ kernel 2
 
 
-// merge_small: at most 64 keys per query (e.g. 4 tiles x top-10): one WAVE per query, keys in registers, ranks by
-// v_readlane broadcasts — no LDS, no barrier, four queries per workgroup.
+// merge_small: one wave per query, four queries per workgroup.
 __global__ __launch_bounds__(256) void merge_small(const MergeArgs a) {
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t q = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (q >= a.nq) return;
-    const uint32_t n_items = a.n_lists * a.k;  // <= 64
-    uint64_t me = 0;
-    if (lane < n_items) {
-        const uint32_t l = lane / a.k, j = lane - l * a.k;
-        me = a.lists[(uint64_t)l * a.list_stride + (uint64_t)q * a.k + j];
-    }
-    const uint32_t lo = (uint32_t)me, hi = (uint32_t)(me >> 32);
-    uint32_t rank = 0;
-    for (uint32_t j = 0; j < n_items; j += 4) {  // lanes past n_items hold key 0, which outranks nobody
-#pragma unroll
-        for (uint32_t u = 0; u < 4; ++u) {
-            const uint64_t o = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)hi, (int)(j + u)) << 32) |
-                               (uint32_t)__builtin_amdgcn_readlane((int)lo, (int)(j + u));
-            rank += o > me;
-        }
-    }
-    const uint32_t n_hit = min((uint32_t)__popcll(__ballot(me != 0)), a.k);
-    // keys are unique, so the non-empty keys take ranks 0 .. n-1; slots [n_hit, k) are empty
-    const uint64_t o = (uint64_t)q * a.k;
-    auto emit = [&](uint32_t i, uint64_t key) {
-        if (a.out_keys) a.out_keys[o + i] = key;
-        if (a.out_ord) {
-            const uint32_t sc = (uint32_t)(key >> 32);
-            a.out_ord[o + i] = key ? 0xFFFFFFFFu - (uint32_t)key : 0xFFFFFFFFu;
-            a.out_score_u32[o + i] = sc;
-            a.out_score[o + i] = (float)sc;  // round-to-nearest-even, exact below 2^24 (contract T5)
-        }
-    };
-    if (me != 0 && rank < a.k) emit(rank, me);
-    if (lane >= n_hit && lane < a.k) emit(lane, 0ull);
-    if (lane == 0 && a.out_n) a.out_n[q] = (int32_t)n_hit;
+    merge_wave(a, q, lane);
 }
 
 template <int NT>

@@ -78,6 +78,12 @@ class DenseIndex:
         indices = np.where(valid, idx.astype(np.int64), -1)
         return scores, indices
 
+    def stats(self):
+        """{'device_allocs': hipMalloc calls made for this handle's scratch, 'scratch_bytes': what it holds}."""
+        out = np.zeros(4, dtype=np.uint64)
+        check(lib().msr_dense_stats(self._h, ptr(out)))
+        return dict(device_allocs=int(out[0]), scratch_bytes=int(out[1]))
+
     def close(self):
         if self._h:
             lib().msr_dense_close(self._h)

@@ -104,6 +104,8 @@ class SparseIndex:
         info = MsrInfo()
         check(lib().msr_index_info(self._h, C.byref(info)))
         self.info = info
+        self._small = {}                       # (nq, k) -> result buffers of small search_csr calls
+        self._search_csr = lib().msr_search_csr
         self.n_docs = int(info.n_docs)
         self.n_terms = int(info.n_terms)
         self.n_postings = int(info.n_postings)
@@ -178,11 +180,23 @@ class SparseIndex:
         """CSR queries -> (ordinals [nq,k] uint32, scores [nq,k] float32, exact scores [nq,k] uint32, n [nq])."""
         q_ptr, q_term, q_w = _cabi.as_csr(q_ptr, q_term, q_w)
         nq = len(q_ptr) - 1
+        flags = MSR_F_DROP_DF_EQ_N if drop_df_eq_n else 0
+        if nq * k <= 1024:
+            # the reference's call shape (4 queries per batch_search, scripts/search_sparse.sh:16): result buffers and
+            # their addresses are kept per (nq, k) — allocating four arrays and taking seven addresses costs such a call
+            # a fifth of its time — and the caller gets copies
+            bufs = self._small.get((nq, k))
+            if bufs is None:
+                arrs = (np.empty((nq, k), np.uint32), np.empty((nq, k), np.float32), np.empty((nq, k), np.uint32),
+                        np.zeros(nq, np.int32))
+                bufs = self._small[(nq, k)] = (arrs, tuple(a.ctypes.data for a in arrs))
+            arrs, addr = bufs
+            check(self._search_csr(self._h, q_ptr.ctypes.data, q_term.ctypes.data, q_w.ctypes.data, nq, int(k), flags, *addr))
+            return tuple(a.copy() for a in arrs)
         ords = np.empty((nq, k), dtype=np.uint32)
         sc = np.empty((nq, k), dtype=np.float32)
         su = np.empty((nq, k), dtype=np.uint32)
         n = np.zeros(nq, dtype=np.int32)
-        flags = MSR_F_DROP_DF_EQ_N if drop_df_eq_n else 0
         check(lib().msr_search_csr(self._h, ptr(q_ptr), ptr(q_term), ptr(q_w), nq, int(k), flags, ptr(ords), ptr(sc),
                                    ptr(su), ptr(n)))
         return ords, sc, su, n
@@ -284,6 +298,15 @@ def runtime_info():
     buf = C.create_string_buffer(2048)
     check(lib().msr_runtime_info(buf, 2048))
     return dict(kv.split("=", 1) for kv in buf.value.decode().split())
+
+
+def search_laps():
+    """Host-side laps (microseconds) of this thread's last msr_search_csr call: see include/msr.h."""
+    out = np.zeros(8, dtype=np.float64)
+    check(lib().msr_search_laps(ptr(out)))
+    names = ("prepare_upload", "enqueue_kernels", "wait_stream", "download", "release", "call_total", "score_kernel",
+             "merge_kernel")
+    return dict(zip(names, (round(float(v), 2) for v in out)))
 
 
 def device_sync(device):

@@ -671,6 +671,30 @@ def test_dense_search_against_numpy(m, n, h, nq, k):
     assert (np.diff(scores[:, :kk], axis=1) <= 0).all()
 
 
+def test_dense_search_steady_state_allocates_nothing(m):
+    """msr_dense_search keeps its device scratch and events on the handle: after the first call of a shape, calls at the
+    reference's batch sizes (--batch_size 2, scripts/search.sh:29; 128, src/arguments.py:60) make no hipMalloc — and
+    give the same answer every time."""
+    from mllm_sparse_retrieval_amd.dense import DenseIndex
+
+    rng = np.random.default_rng(2)
+    p, q = _unit_rows(rng, 9000, 64), _unit_rows(rng, 128, 64)
+    dix = DenseIndex(p)
+    first = {}
+    for bs in (2, 128):
+        first[bs] = dix.search(q[:bs], 100)
+    base = dix.stats()["device_allocs"]
+    assert base > 0
+    for _ in range(5):
+        for bs in (2, 128):
+            s, i = dix.search(q[:bs], 100)
+            assert (s == first[bs][0]).all() and (i == first[bs][1]).all()
+    assert dix.stats()["device_allocs"] == base
+    ws, wi = _dense_oracle(q, p, 100)
+    assert np.abs(first[128][0] - ws).max() <= 1e-5
+    dix.close()
+
+
 def test_dense_gemm_random_shapes(m):
     """The four-wave GEMM kernel (grids of >= 256 blocks of 256 x 256) on random shapes: ragged last blocks in both
     directions, 1-8 steps of 64 in K, doc counts that are not multiples of 4; scores within 1e-5 of numpy on the
