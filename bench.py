@@ -55,7 +55,8 @@ L2_PEAK_GBS = 34500.0    # aggregate L2 -> CU bandwidth (8 XCDs)
 MFMA_F16_PEAK_TF = 2500.0  # dense fp16/bf16 MFMA peak
 N_SIMDS = 1024           # 256 CUs x 4 SIMDs
 N_XCDS = 8
-COUNTERS_FILE = os.path.join(ROOT, "profiles", "r02_counters.json")
+COUNTERS_FILE = os.path.join(ROOT, "profiles", "r03_counters.json")
+LDS_PEAK_GBS = 256 * 128 * 2.4  # 128 B / clk / CU x 256 CUs x 2.4 GHz = 78.6 TB/s (guide figure; the measured one is used)
 
 EXIT_LAUNCH = 2   # bad launch: fewer GPUs than ranks, WORLD_SIZE / --gpus mismatch
 EXIT_HUNG = 3     # the multi-rank exchange did not finish (watchdog)
@@ -231,13 +232,14 @@ _M = None
 def device_sync():
     """Contract: a device-wide fence on both sides of the timed region, on THIS rank's GPU: hipDeviceSynchronize
     through libmsr.so (covers libmsr's own stream) and torch.cuda.synchronize() as the contract names it. No other
-    torch GPU call is made in this process: torch's bundled kernels expect torch's own (older) HIP runtime, while the
-    process runs on the /opt/rocm runtime libmsr.so was built for."""
+    torch GPU call is made in this process (tests/test_cabi.py greps for it): torch's bundled kernels expect torch's
+    own (older) HIP runtime, while the process runs on the /opt/rocm runtime libmsr.so was built for — round 2's 20
+    segfaults under rocprofv3 were torch device-to-device copies on that foreign runtime."""
     _M.device_sync(_SYNC_DEVICE)
     try:
         import torch
 
-        if torch.cuda.is_available():
+        if torch.cuda.device_count() > _SYNC_DEVICE:   # (device_count does not initialise the GPU; is_available does)
             torch.cuda.synchronize(_SYNC_DEVICE)
     except Exception:
         pass
@@ -287,18 +289,39 @@ def timed_steps(batch, k, steps, warmup, ranks, sharded=False, step=None):
 
 # ------------------------------------------------------------------------------------------------ roofline
 _COUNTERS = None
+_COUNTERS_STATE = None
+
+
+def counters_state():
+    """Is profiles/r03_counters.json about THIS binary? The file carries the kernel-source and code-object hashes of the
+    build it was collected on (scripts/prof_counters.py); when they differ from this tree's, every counter-backed figure
+    is withheld and the bench line says `counters_stale`."""
+    global _COUNTERS, _COUNTERS_STATE
+    if _COUNTERS_STATE is None:
+        from mllm_sparse_retrieval_amd import _buildinfo
+
+        try:
+            _COUNTERS = json.load(open(COUNTERS_FILE))
+        except Exception as e:
+            _COUNTERS = {}
+            _COUNTERS_STATE = {"file": os.path.relpath(COUNTERS_FILE, ROOT), "stale": True, "reason": f"unreadable: {e}"}
+            return _COUNTERS_STATE
+        st = _COUNTERS.get("_stamp")
+        reason = _buildinfo.stale_reason(st)
+        _COUNTERS_STATE = {"file": os.path.relpath(COUNTERS_FILE, ROOT), "stale": reason is not None,
+                           "collected_at_git_head": (st or {}).get("git_head"),
+                           "kernel_source_sha256": (st or {}).get("kernel_source_sha256")}
+        if reason:
+            _COUNTERS_STATE["reason"] = reason
+            _COUNTERS = {}
+    return _COUNTERS_STATE
 
 
 def counters(workload, kernel_re):
     """Per-STEP counter sums of the kernels matching `kernel_re` in one profiled workload, from the committed
-    rocprofv3 --pmc passes (profiles/r02_counters.json, written by scripts/prof_counters.py; one pass per counter
-    group, as MI355X_MICROARCH.md prescribes). None when the workload was not profiled."""
-    global _COUNTERS
-    if _COUNTERS is None:
-        try:
-            _COUNTERS = json.load(open(COUNTERS_FILE))
-        except Exception:
-            _COUNTERS = {}
+    rocprofv3 --pmc passes (profiles/r03_counters.json, written by scripts/prof_counters.py; one pass per counter
+    group, as MI355X_MICROARCH.md prescribes). None when the workload was not profiled or the file is stale."""
+    counters_state()
     w = _COUNTERS.get(workload)
     if not w:
         return None
@@ -311,6 +334,23 @@ def counters(workload, kernel_re):
         return None
     steps = float(w.get("steps", 1))
     return {key: v / steps for key, v in tot.items()}
+
+
+_PEAKS = None
+
+
+def pipe_peaks():
+    """The pipes the scorer's useful work runs on, MEASURED on this rank's GPU at the kernel's launch shape
+    (msr_device_peak_rates: kernels that issue nothing but ds_add_u32 / v_dot2_u32_u16 / the accumulator tile's
+    ds_write_b128 + 2 x ds_read_b128)."""
+    global _PEAKS
+    if _PEAKS is None:
+        try:
+            _PEAKS = _M.device_peak_rates(_SYNC_DEVICE)
+        except Exception as e:
+            log(f"[bench] peak-rate measurement failed: {e}")
+            _PEAKS = {}
+    return _PEAKS
 
 
 def binding_fractions(c, kernel_ms):
@@ -355,37 +395,69 @@ def binding_fractions(c, kernel_ms):
 
 
 def sparse_roofline(batch, k, score_ms_avg, workload_name, kernel_re="score_tiles"):
-    """roofline object of the sparse scorer: the binding ceiling is whichever of {HBM traffic, L2 -> CU bytes, VALU
-    issue} the counters put highest; SURVEY §8d's algorithmic-bytes figure is kept beside it, labelled for what it is."""
+    """roofline object of the sparse scorer.
+
+    frac = USEFUL-WORK roofline: the least time the step's work needs on the pipe that binds it, over the kernel time
+    measured live. The work is what any (tile, query) decomposition of this algorithm has to do, each part priced at the
+    MEASURED peak of the instruction that does it (pipe_peaks):
+        lds_atomic  inverted-list postings        / ds_add_u32 lane-ops per second
+        valu_dot2   dense-head postings / 2       / v_dot2_u32_u16 lane-ops per second
+        lds_bw      accumulator tiles: init write + the selection's two reads  / LDS bytes per second at that mix
+        hbm         HBM-side bytes (counters)     / 8 TB/s
+    `utilisation` keeps the pipe-busy figures of round 2 (how busy, not how useful), `algorithmic` SURVEY §8d's number."""
     by, postings = batch.algo_bytes(k)
-    algo_gbs = by / (score_ms_avg * 1e-3) / 1e9 if score_ms_avg > 0 else 0.0
+    t = score_ms_avg * 1e-3
+    algo_gbs = by / t / 1e9 if t > 0 else 0.0
+    state = counters_state()
     fr = binding_fractions(counters(workload_name, kernel_re), score_ms_avg)
-    cands = {"hbm": fr.get("hbm_frac"), "l2": fr.get("l2_frac"), "valu": fr.get("valu_busy")}
-    cands = {b: v for b, v in cands.items() if v is not None}
+    work = batch.work()
+    pk = pipe_peaks()
     r = {"kernel": "score_tiles", "kernel_ms": round(score_ms_avg, 4),
          "launches_per_step": 2 if batch.index.n_tiles >= 2 else 1}
-    if cands:
-        bound = max(cands, key=cands.get)
-        r["bound"] = bound
-        r["frac"] = cands[bound]
-        if bound == "hbm":
-            r.update(achieved=round(fr["traffic"] / (score_ms_avg * 1e-3) / 1e9, 1), peak=HBM_PEAK_GBS, unit="GB/s")
-        elif bound == "l2":
-            r.update(achieved=round(fr["l2_hit_bytes"] / (score_ms_avg * 1e-3) / 1e9, 1), peak=L2_PEAK_GBS, unit="GB/s")
-        else:
-            r.update(achieved=round(100.0 * fr["valu_busy"], 2), peak=100.0, unit="% of VALU issue cycles")
+    min_ms = {}
+    if pk.get("ds_add_per_s"):
+        min_ms["lds_atomic"] = work["sparse_postings"] / pk["ds_add_per_s"] * 1e3
+        min_ms["valu_dot2"] = work["dense_head_postings"] / 2.0 / pk["dot2_per_s"] * 1e3
+        min_ms["lds_bw"] = (work["acc_init_bytes"] + work["acc_select_bytes"]) / pk["lds_bytes_per_s"] * 1e3
+    if fr.get("traffic") is not None:
+        min_ms["hbm"] = fr["traffic"] / (HBM_PEAK_GBS * 1e9) * 1e3
+    complete = len(min_ms) == 4 and not state["stale"] and t > 0
+    if min_ms:
+        bound = max(min_ms, key=min_ms.get)
+        useful = min_ms[bound] / score_ms_avg if score_ms_avg > 0 else None
+        achieved, peak, unit = {
+            "lds_atomic": (work["sparse_postings"] / t / 1e9, pk.get("ds_add_per_s", 0) / 1e9, "G postings/s (ds_add_u32 lane-ops)"),
+            "valu_dot2": (work["dense_head_postings"] / 2.0 / t / 1e9, pk.get("dot2_per_s", 0) / 1e9, "G v_dot2_u32_u16 lane-ops/s"),
+            "lds_bw": ((work["acc_init_bytes"] + work["acc_select_bytes"]) / t / 1e9, pk.get("lds_bytes_per_s", 0) / 1e9, "GB/s (LDS)"),
+            "hbm": ((fr.get("traffic") or 0) / t / 1e9, HBM_PEAK_GBS, "GB/s"),
+        }[bound]
+        r.update(bound=bound, achieved=round(achieved, 1), peak=round(peak, 1), unit=unit,
+                 frac=round(useful, 4) if complete else None)
+        r["useful"] = {"min_ms_per_pipe": {b: round(v, 4) for b, v in min_ms.items()},
+                       "frac_if_counters_were_current": None if complete else (round(useful, 4) if useful else None),
+                       "work_per_step": work,
+                       "peaks_measured": {"ds_add_u32_lane_ops_per_s": pk.get("ds_add_per_s"),
+                                          "v_dot2_u32_u16_lane_ops_per_s": pk.get("dot2_per_s"),
+                                          "lds_bytes_per_s_1w2r": pk.get("lds_bytes_per_s"), "cus": pk.get("cus"),
+                                          "how": "msr_device_peak_rates on this GPU, in this run (profiles/r03_peak_rates.txt)"},
+                       "note": "frac = the binding pipe's minimum time / kernel time: what share of the kernel's life the "
+                               "postings' own adds / dot products / accumulator traffic would need at the measured "
+                               "instruction peaks; the rest is per-(tile, query) fixed cost, address arithmetic and waits"}
+        if complete is False and r["useful"]["frac_if_counters_were_current"] is None:
+            r["useful"].pop("frac_if_counters_were_current")
     else:
         r.update(bound="hbm", frac=None, achieved=None, peak=HBM_PEAK_GBS, unit="GB/s")
-    r.update({key: fr.get(key) for key in ("hbm_frac", "l2_frac", "valu_busy", "salu_per_valu", "lds_issue_busy",
-                                            "l2_hit_rate")})
+    r["counters_stale"] = bool(state["stale"])
     r["traffic"] = fr.get("traffic")
+    r["utilisation"] = {key: fr.get(key) for key in ("hbm_frac", "l2_frac", "valu_busy", "salu_per_valu", "lds_issue_busy",
+                                                      "l2_hit_rate", "clock_ghz")}
     r["algorithmic"] = {"bytes_per_step": by, "postings_per_step": postings, "gbps": round(algo_gbs, 1),
                         "over_hbm_peak": round(algo_gbs / HBM_PEAK_GBS, 4),
                         "note": "SURVEY §8d bytes (6 B per posting, every query streams privately) / kernel time: NOT a "
                                 "ceiling for a query-batched scorer — a tile's postings are shared by the queries in "
                                 "flight through L2, stored as 4-byte postings / 2-byte dense-head weights"}
     r["hbm_copy_measured"] = hbm_copy_gbs()
-    r["counters_source"] = "profiles/r02_counters.json (rocprofv3 --pmc, separate passes; scripts/prof_counters.py)"
+    r["counters"] = state
     return r
 
 
@@ -418,7 +490,7 @@ def cpu_baseline(wl, got, target_seconds, threads, rows=True):
     def sub(a, b):
         return (qp[a: b + 1] - qp[a]), qt[qp[a]: qp[b]], qw[qp[a]: qp[b]]
 
-    def sized(thr, per_call=None):
+    def sized(thr, per_call=None, mode="exhaustive"):
         """queries that fill ~target_seconds at this setting (from a short probe)"""
         probe = min(nq, max(4 * thr, 64))
         t1 = time.perf_counter()
@@ -426,7 +498,7 @@ def cpu_baseline(wl, got, target_seconds, threads, rows=True):
             for a in range(0, probe, per_call):
                 oix.search(*sub(a, min(a + per_call, probe)), wl.k, threads=thr)
         else:
-            oix.search(*sub(0, probe), wl.k, threads=thr)
+            oix.search(*sub(0, probe), wl.k, threads=thr, mode=mode)
         per_q = (time.perf_counter() - t1) / probe
         return int(min(nq, max(probe, target_seconds / max(per_q, 1e-9))))
 
@@ -448,12 +520,30 @@ def cpu_baseline(wl, got, target_seconds, threads, rows=True):
         extra = []
         thr_all = max(1, min(affinity, 256))
         if thr_all != threads:
-            n2 = sized(thr_all)
+            # every CPU this job may run on. The accumulators are scanned and cleared over the docs a query touched only
+            # (mode "touched": with a full 4-byte-per-doc scan + memset per query, 256 workers thrash the caches and run
+            # SLOWER than 16 — round 2's row); same hits as the exhaustive scan (tests/test_oracle.py)
+            n2 = sized(thr_all, mode="touched")
             t0 = time.perf_counter()
-            oix.search(*sub(0, n2), wl.k, threads=thr_all)
+            r2 = oix.search(*sub(0, n2), wl.k, threads=thr_all, mode="touched")
             d2 = time.perf_counter() - t0
+            nn = min(n, n2)
             extra.append({"value": round(n2 / d2, 1), "cores": thr_all, "queries": n2, "seconds": round(d2, 2),
-                          "shape": f"one call, {thr_all} threads = every CPU this job may run on (sched_getaffinity)"})
+                          "kind": "port", "identical_to_exhaustive": bool((r2[0][:nn] == w_ord[:nn]).all() and (r2[1][:nn] == w_sc[:nn]).all()),
+                          "shape": f"one call, {thr_all} threads = every CPU this job may run on (sched_getaffinity); "
+                                   f"term-at-a-time, only touched docs scanned and cleared"})
+        # a PRUNING engine on the same host: document-at-a-time MaxScore in 4096-doc windows (the strategy of Lucene's
+        # bulk scorer for pure disjunctions), exact, same file. With ~flat learned-sparse weights few lists ever become
+        # non-essential at k = 10, so pruning does not beat the exhaustive scan here: reported, not assumed.
+        n4 = sized(threads, mode="maxscore")
+        t0 = time.perf_counter()
+        r4 = oix.search(*sub(0, n4), wl.k, threads=threads, mode="maxscore")
+        d4 = time.perf_counter() - t0
+        nn = min(n, n4)
+        extra.append({"value": round(n4 / max(d4, 1e-9), 1), "cores": threads, "queries": n4, "seconds": round(d4, 2),
+                      "kind": "port+pruning",
+                      "identical_to_exhaustive": bool((r4[0][:nn] == w_ord[:nn]).all() and (r4[1][:nn] == w_sc[:nn]).all()),
+                      "shape": f"one call, {threads} threads, document-at-a-time MaxScore (oracle_taat.c mode 2): exact top-{wl.k}"})
         n3 = sized(threads, per_call=4) // 4 * 4
         t0 = time.perf_counter()
         for a in range(0, n3, 4):
@@ -849,7 +939,7 @@ def run_c5(args, ranks, m, wlmod, shape="t2i"):
         tf = flops / (ms["dense_gemm"] * 1e-3) / 1e12
         rl["dense_gemm"] = {"bound": "mfma", "achieved": round(tf, 1), "peak": MFMA_F16_PEAK_TF, "unit": "TFLOP/s",
                             "frac": round(tf / MFMA_F16_PEAK_TF, 4), "kernel_ms": round(ms["dense_gemm"], 4),
-                            **binding_fractions(counters(wname, "dense_scores"), ms["dense_gemm"])}
+                            "utilisation": binding_fractions(counters(wname, "dense_scores"), ms["dense_gemm"])}
     stages = ((("hybrid_tiles", "hybrid_tiles", "sparse"),) if fused else
               (("hybrid_tiles_mode1", "hybrid_tiles", "sparse"), ("hybrid_fuse_query", "hybrid_fuse_query", "fusion")) if multi else
               (("dense_select", "select_tiles", "dense_select"), ("fusion", "fuse_tiles", "fusion"),
@@ -860,8 +950,11 @@ def run_c5(args, ranks, m, wlmod, shape="t2i"):
             cands = {b: fr.get(k3) for b, k3 in (("hbm", "hbm_frac"), ("l2", "l2_frac"), ("valu", "valu_busy"))
                      if fr.get(k3) is not None}
             bound = max(cands, key=cands.get) if cands else None
-            rl[stage] = {"bound": bound, "frac": cands.get(bound) if bound else None, "kernel_ms": round(ms[key], 4), **fr}
+            # (pipe utilisation — how busy, not how useful: no `frac` is claimed for these kernels)
+            rl[stage] = {"bound": bound, "frac": None, "busiest_pipe_utilisation": cands.get(bound) if bound else None,
+                         "kernel_ms": round(ms[key], 4), "utilisation": fr}
     out["roofline"] = rl
+    out["counters_stale"] = bool(counters_state()["stale"])
     if not args.no_cpu and shape == "i2t":
         # the dense search alone at the batch sizes the reference runs it with (PCIe-inclusive: host f32 queries in, host
         # lists out): --batch_size 2 (scripts/search.sh:29) and the default 128 (src/arguments.py:60)

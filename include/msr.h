@@ -165,6 +165,11 @@ int msr_batch_debug_stamps(msr_batch* b, unsigned long long out[8]);
 /* Algorithmic bytes of one search of this batch, SURVEY.md §8d:
  * sum over queries of  sum_t df(t)*(4+2) + |q|*12 + k*8  (df restricted to this handle's shard). */
 int msr_batch_algo_bytes(const msr_batch* b, int k, uint64_t* bytes, uint64_t* postings);
+/* The work one search of this batch does, for the roofline of the scoring kernel (no reference counterpart):
+ * out = {postings walked through inverted lists (one LDS add each), postings scored out of the dense head (half a
+ * v_dot2_u32_u16 each), (tile, query) workgroups, LDS bytes written to initialise the accumulator tiles, LDS bytes the
+ * selection reads back (two passes), kept query entries}. */
+int msr_batch_work(const msr_batch* b, uint64_t out[6]);
 void msr_batch_destroy(msr_batch* b);
 
 /* ---- multi-GPU exchange (doc-range shards, one RCCL all-gather of per-shard top-k) ----
@@ -185,6 +190,10 @@ int msr_device_sync(int device);
 /* Bandwidth of a device-to-device copy of `bytes` (read + write bytes / time, GB/s): the measured HBM figure quoted
  * beside the vendor peak in the benchmark record. */
 int msr_device_copy_gbs(int device, uint64_t bytes, int reps, double* gbs);
+/* Measured peaks of the pipes the scoring kernel's useful work runs on, at its launch shape (512 threads, four
+ * workgroups per CU): out = {ds_add_u32 lane operations / s, v_dot2_u32_u16 lane operations / s, LDS bytes / s at one
+ * 16-byte write per two 16-byte reads, CUs}. Takes a few milliseconds. */
+int msr_device_peak_rates(int device, double out[4]);
 
 /* Term-range shards (the north star's partition; exact protocol of DESIGN.md §6): the batch holds only the query terms
  * of term range `shard` of `n_shards` (ranges are contiguous in term id and balanced by postings). Search = dump the

@@ -70,6 +70,7 @@ SYMBOLS = [
     ("msr_batch_timing_sum", _I, [_VP, C.POINTER(_I), C.POINTER(C.c_float), C.POINTER(C.c_float)]),
     ("msr_batch_debug_stamps", _I, [_VP, _VP]),
     ("msr_batch_algo_bytes", _I, [_VP, _I, C.POINTER(_U64), C.POINTER(_U64)]),
+    ("msr_batch_work", _I, [_VP, _VP]),
     ("msr_batch_destroy", None, [_VP]),
     ("msr_comm_unique_id", _I, [_VP]),
     ("msr_comm_init", _I, [_VP, _I, _I, _VP]),
@@ -83,6 +84,7 @@ SYMBOLS = [
     ("msr_runtime_info", _I, [_VP, _I]),
     ("msr_device_sync", _I, [_I]),
     ("msr_device_copy_gbs", _I, [_I, _U64, _I, C.POINTER(C.c_double)]),
+    ("msr_device_peak_rates", _I, [_I, _VP]),
     ("msr_merge_lists", _I, [_VP, _I, _I, _I, _VP, _VP, _VP, _VP, _VP, _VP, _VP]),
     ("msr_dense_open", _I, [_VP, _U64, _U32, _I, C.POINTER(_VP)]),
     ("msr_dense_search", _I, [_VP, _VP, _I, _I, _VP, _VP, _VP, C.POINTER(C.c_float), C.POINTER(C.c_float)]),

@@ -451,7 +451,7 @@ static int batch_create_impl(msr_index* ix, const int64_t* q_ptr, const int32_t*
     struct Part {
         int q0 = 0, q1 = 0;
         std::vector<uint32_t> term, w;
-        uint64_t n_kept = 0, sum_df = 0, max_sparse = 0;
+        uint64_t n_kept = 0, sum_df = 0, sum_df_dense = 0, max_sparse = 0;
         int rc = MSR_OK;
         char err[192] = {0};
     };
@@ -491,6 +491,7 @@ static int batch_create_impl(msr_index* ix, const int64_t* q_ptr, const int32_t*
                 pt.sum_df += d->df_shard[t];
                 ++pt.n_kept;
                 const int ds = ix->host.dense_slot[t];
+                if (ds >= 0) pt.sum_df_dense += d->df_shard[t];
                 if (ds >= 0) {  // dense-head term: repeated entries add up; v_dot2_u32_u16 takes 16-bit weights
                     if ((uint64_t)dsum[ds] + (uint64_t)w > 0xFFFFull)
                         return bad(MSR_E_RANGE, "query %d: weight of dense-head term %d exceeds the supported maximum 65535", i, t);
@@ -516,7 +517,7 @@ static int batch_create_impl(msr_index* ix, const int64_t* q_ptr, const int32_t*
     };
     parallel_run(n_parts, normalise);
     uint64_t n_kept = 0;
-    uint64_t sum_df = 0;
+    uint64_t sum_df = 0, sum_df_dense = 0;
     uint64_t max_sparse = 0;  // most sparse (non dense-head) terms in one query
     uint64_t n_sparse = 0;
     for (const Part& pt : parts) {  // parts are in query order: the first failing part holds the lowest failing query
@@ -526,6 +527,7 @@ static int batch_create_impl(msr_index* ix, const int64_t* q_ptr, const int32_t*
         }
         n_kept += pt.n_kept;
         sum_df += pt.sum_df;
+        sum_df_dense += pt.sum_df_dense;
         max_sparse = std::max(max_sparse, pt.max_sparse);
         n_sparse += pt.term.size();
     }
@@ -564,6 +566,7 @@ static int batch_create_impl(msr_index* ix, const int64_t* q_ptr, const int32_t*
     b->term_shard = n_shards > 0 ? shard : -1;
     b->term_nshards = n_shards > 0 ? n_shards : 0;
     b->sum_df = sum_df;
+    b->sum_df_dense = sum_df_dense;
     b->max_sparse_terms = (uint32_t)std::min<uint64_t>(max_sparse, 0xFFFFFFFFull);
     auto fail = [&](int rc) {
         batch_free(b);
@@ -920,6 +923,29 @@ int msr_batch_algo_bytes(const msr_batch* b, int k, uint64_t* bytes, uint64_t* p
     // bytes(q) = sum_t df(t)*(4+2) + |q|*12 + k*8
     if (bytes) *bytes = b->sum_df * 6 + b->nnz * 12 + (uint64_t)b->nq * k * 8;
     if (postings) *postings = b->sum_df;
+    return MSR_OK;
+}
+
+int msr_batch_work(const msr_batch* b, uint64_t out[6]) {
+    if (!b || !out || !b->ix) {
+        set_error("msr_batch_work: bad argument");
+        return MSR_E_INVAL;
+    }
+    const msr_index* ix = b->ix;
+    const IndexHeader* h = ix->host.h;
+    // threads of the scoring instance (4 accumulators per thread and round)
+    const uint64_t nt = h->tile_docs == 4096 ? 256 : (h->tile_docs == 32768 ? 1024 : 512);
+    uint64_t acc_words = 0;  // accumulators one query initialises (and selects over) across the shard's tiles
+    for (uint32_t t = ix->shard_tile0; t < ix->shard_tile0 + ix->shard_ntiles; ++t) {
+        const uint64_t docs = std::min<uint64_t>(h->tile_docs, h->n_docs - (uint64_t)t * h->tile_docs);
+        acc_words += (docs + 4 * nt - 1) / (4 * nt) * (4 * nt);
+    }
+    out[0] = b->sum_df - b->sum_df_dense;                 // postings walked through the inverted lists (one ds_add_u32 each)
+    out[1] = b->sum_df_dense;                             // postings scored out of the dense head (half a v_dot2_u32_u16 each)
+    out[2] = (uint64_t)ix->shard_ntiles * (uint64_t)b->nq;  // (tile, query) workgroups
+    out[3] = acc_words * 4 * (uint64_t)b->nq;             // LDS bytes written to initialise the accumulator tiles
+    out[4] = 2 * acc_words * 4 * (uint64_t)b->nq;         // LDS bytes read back by the selection (maxima pass + candidate pass)
+    out[5] = b->nnz;                                      // kept query entries
     return MSR_OK;
 }
 
@@ -1530,6 +1556,131 @@ int msr_device_sync(int device) {
     HIP_TRY(hipSetDevice(device));
     HIP_TRY(hipDeviceSynchronize());
     return MSR_OK;
+}
+
+}  // extern "C"
+
+// ------------------------------------------------------------------------------------------------ pipe peaks
+// The instruction rates the scorer's useful work is priced against (bench.py: roofline.useful), MEASURED on the device
+// the benchmark runs on: each kernel issues nothing but the instruction in question (plus its loop), at the production
+// kernel's shape (512 threads, 32 KiB of LDS per workgroup: four workgroups = 32 waves per CU).
+namespace msr {
+
+// ds_add_u32 without return, 64 lanes on 64 consecutive words (two per bank: the layout the indexer arranges postings
+// for); sixteen adds per iteration at immediate offsets from one address register
+__global__ __launch_bounds__(512, 8) void peak_ds_add(uint32_t* out, int iters) {
+    __shared__ uint32_t acc[8192];
+    const uint32_t tid = threadIdx.x;
+    for (int i = tid; i < 8192; i += 512) acc[i] = 0;
+    __syncthreads();
+    uint32_t* const mine = acc + tid;
+    for (int i = 0; i < iters; ++i) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) atomicAdd(mine + 512 * e, (uint32_t)i);
+    }
+    __syncthreads();
+    if (acc[tid] == 0xFFFFFFFFu) out[blockIdx.x] = acc[tid];
+}
+
+// v_dot2_u32_u16: eight independent accumulator chains per lane
+__global__ __launch_bounds__(512, 8) void peak_dot2(uint32_t* out, int iters, uint32_t seed) {
+    typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+    uint32_t a[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) a[e] = threadIdx.x + e;
+    const us2 q = __builtin_bit_cast(us2, seed);
+    uint32_t x = seed ^ threadIdx.x;
+    for (int i = 0; i < iters; ++i) {
+        const us2 w = __builtin_bit_cast(us2, x);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) a[e] = __builtin_amdgcn_udot2(w, q, a[e], false);
+        x += 0x00010001u;
+    }
+    uint32_t s = 0;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) s ^= a[e];
+    if (s == 0xDEADBEEFu) out[blockIdx.x] = s;
+}
+
+// the accumulator traffic of one (tile, query): one ds_write_b128 (init) and two ds_read_b128 (selection passes) per vec,
+// thread `tid` on vec r * 512 + tid like the kernels (conflict-free); inline asm so that exactly these are issued
+__global__ __launch_bounds__(512, 8) void peak_lds_rw(uint32_t* out, int iters) {
+    __shared__ __attribute__((aligned(16))) uint4 acc4[2048];
+    const uint32_t tid = threadIdx.x;
+    const uint32_t addr = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)(acc4 + tid);
+    u32x4 v = {tid, 1u, 2u, 3u};
+    u32x4 s = {0u, 0u, 0u, 0u};
+    for (int i = 0; i < iters; ++i) {
+        u32x4 x[8];
+        asm volatile("ds_write_b128 %0, %1\n\tds_write_b128 %0, %1 offset:8192\n\tds_write_b128 %0, %1 offset:16384\n\t"
+                     "ds_write_b128 %0, %1 offset:24576" ::"v"(addr), "v"(v) : "memory");
+        asm volatile("ds_read_b128 %0, %8\n\tds_read_b128 %1, %8 offset:8192\n\tds_read_b128 %2, %8 offset:16384\n\t"
+                     "ds_read_b128 %3, %8 offset:24576\n\tds_read_b128 %4, %8\n\tds_read_b128 %5, %8 offset:8192\n\t"
+                     "ds_read_b128 %6, %8 offset:16384\n\tds_read_b128 %7, %8 offset:24576\n\ts_waitcnt lgkmcnt(0)"
+                     : "=&v"(x[0]), "=&v"(x[1]), "=&v"(x[2]), "=&v"(x[3]), "=&v"(x[4]), "=&v"(x[5]), "=&v"(x[6]), "=&v"(x[7])
+                     : "v"(addr)
+                     : "memory");
+        s ^= x[0] ^ x[1] ^ x[2] ^ x[3] ^ x[4] ^ x[5] ^ x[6] ^ x[7];
+        v.x += s.x;
+    }
+    if ((s.x ^ s.y ^ s.z ^ s.w) == 0xDEADBEEFu) out[blockIdx.x] = s.x;
+}
+
+}  // namespace msr
+
+extern "C" {
+
+int msr_device_peak_rates(int device, double out[4]) {
+    if (!out) {
+        set_error("msr_device_peak_rates: null output");
+        return MSR_E_INVAL;
+    }
+    int n_dev = 0;
+    if (device < 0 || hipGetDeviceCount(&n_dev) != hipSuccess || device >= n_dev) {
+        set_error("no usable HIP device %d", device);
+        return MSR_E_NODEVICE;
+    }
+    HIP_TRY(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device));
+    const uint32_t n_wg = (uint32_t)std::max(prop.multiProcessorCount, 1) * 4u * 4u;  // four rounds of four workgroups per CU
+    uint32_t* d_out = nullptr;
+    hipStream_t st = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    int rc = MSR_OK;
+    bool ok = hipMalloc(&d_out, (size_t)n_wg * 4) == hipSuccess && hipStreamCreateWithFlags(&st, hipStreamNonBlocking) == hipSuccess &&
+              hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess;
+    auto timed = [&](auto launch) -> double {  // best of five, seconds
+        double best = 1e30;
+        for (int rep = 0; rep < 6 && ok; ++rep) {
+            ok = hipEventRecord(e0, st) == hipSuccess;
+            launch();
+            float ms = 0;
+            ok = ok && hipGetLastError() == hipSuccess && hipEventRecord(e1, st) == hipSuccess &&
+                 hipStreamSynchronize(st) == hipSuccess && hipEventElapsedTime(&ms, e0, e1) == hipSuccess;
+            if (rep > 0 && ms > 0) best = std::min(best, (double)ms * 1e-3);
+        }
+        return best;
+    };
+    const double lanes = (double)n_wg * 512.0;
+    const int it_add = 2000, it_dot = 20000, it_lds = 4000;
+    double t;
+    t = ok ? timed([&] { hipLaunchKernelGGL(peak_ds_add, dim3(n_wg), dim3(512), 0, st, d_out, it_add); }) : 0;
+    out[0] = ok ? lanes * it_add * 16.0 / t : 0;   // ds_add_u32 lane operations per second = inverted-list postings / s
+    t = ok ? timed([&] { hipLaunchKernelGGL(peak_dot2, dim3(n_wg), dim3(512), 0, st, d_out, it_dot, 0x00030002u); }) : 0;
+    out[1] = ok ? lanes * it_dot * 8.0 / t : 0;    // v_dot2_u32_u16 lane operations per second (two dense-head postings each)
+    t = ok ? timed([&] { hipLaunchKernelGGL(peak_lds_rw, dim3(n_wg), dim3(512), 0, st, d_out, it_lds); }) : 0;
+    out[2] = ok ? lanes * it_lds * 12.0 * 16.0 / t : 0;  // LDS bytes per second at the 1 write : 2 reads mix of an accumulator tile
+    out[3] = (double)prop.multiProcessorCount;
+    if (!ok) {
+        set_error("peak-rate measurement failed: %s", hipGetErrorString(hipGetLastError()));
+        rc = MSR_E_HIP;
+    }
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    if (st) (void)hipStreamDestroy(st);
+    if (d_out) (void)hipFree(d_out);
+    return rc;
 }
 
 int msr_device_copy_gbs(int device, uint64_t bytes, int reps, double* gbs) {

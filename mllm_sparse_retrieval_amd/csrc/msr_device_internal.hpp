@@ -181,6 +181,7 @@ struct msr_batch {
     int last_k = 0;
     uint64_t nnz = 0;             // kept query entries
     uint64_t sum_df = 0;          // sum over kept entries of df_shard(term)
+    uint64_t sum_df_dense = 0;    // ... of which the dense-head terms' (scored doc-major, no inverted list)
     uint32_t max_sparse_terms = 0; // most sparse (non dense-head) terms in one query: <= 64 selects the light kernel
     uint32_t* d_qptr = nullptr;
     uint32_t* d_qterm = nullptr;

@@ -320,6 +320,13 @@ def device_copy_gbs(device, nbytes=1 << 30, reps=8):
     return g.value
 
 
+def device_peak_rates(device):
+    """Measured pipe peaks at the scoring kernel's launch shape: {'ds_add_per_s', 'dot2_per_s', 'lds_bytes_per_s', 'cus'}."""
+    out = np.zeros(4, dtype=np.float64)
+    check(lib().msr_device_peak_rates(int(device), ptr(out)))
+    return dict(ds_add_per_s=float(out[0]), dot2_per_s=float(out[1]), lds_bytes_per_s=float(out[2]), cus=int(out[3]))
+
+
 def comm_unique_id():
     buf = C.create_string_buffer(_cabi.MSR_COMM_ID_BYTES)
     check(lib().msr_comm_unique_id(buf))
@@ -385,6 +392,13 @@ class QueryBatch:
         out = np.zeros(8, dtype=np.uint64)
         check(lib().msr_batch_debug_stamps(self._h, ptr(out)))
         return out
+
+    def work(self):
+        """The work of one search of this batch (msr_batch_work): postings by pipe, workgroups, accumulator LDS bytes."""
+        out = np.zeros(6, dtype=np.uint64)
+        check(lib().msr_batch_work(self._h, ptr(out)))
+        return dict(sparse_postings=int(out[0]), dense_head_postings=int(out[1]), workgroups=int(out[2]),
+                    acc_init_bytes=int(out[3]), acc_select_bytes=int(out[4]), query_entries=int(out[5]))
 
     def algo_bytes(self, k):
         by, po = C.c_uint64(), C.c_uint64()

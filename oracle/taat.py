@@ -28,6 +28,9 @@ def lib():
         L.otaat_search.restype = C.c_int
         L.otaat_search.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
                                    C.c_void_p, C.c_void_p, C.c_void_p]
+        L.otaat_search_mode.restype = C.c_int
+        L.otaat_search_mode.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
+                                        C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
         L.otaat_n_postings.restype = C.c_uint64
         L.otaat_n_postings.argtypes = [C.c_void_p]
         _LIB = L
@@ -63,7 +66,11 @@ class TaatIndex:
         gather = starts + within
         return cls(new_ptr, np.asarray(term)[gather], np.asarray(weight)[gather], n_terms), order
 
-    def search(self, q_ptr, q_term, q_w, k, drop_df_eq_n=True, threads=1):
+    MODES = {"exhaustive": 0, "touched": 1, "maxscore": 2}
+
+    def search(self, q_ptr, q_term, q_w, k, drop_df_eq_n=True, threads=1, mode="exhaustive"):
+        """mode: 'exhaustive' (TAAT, full accumulator scan: the checker), 'touched' (TAAT, only touched docs scanned and
+        cleared) or 'maxscore' (document-at-a-time MaxScore pruning). All three return the same hits."""
         q_ptr = np.ascontiguousarray(q_ptr, dtype=np.int64)
         q_term = np.ascontiguousarray(q_term, dtype=np.int32)
         q_w = np.ascontiguousarray(q_w, dtype=np.int32)
@@ -71,9 +78,9 @@ class TaatIndex:
         ords = np.empty((nq, k), dtype=np.int64)
         scores = np.empty((nq, k), dtype=np.int64)
         n = np.zeros(nq, dtype=np.int32)
-        rc = lib().otaat_search(self._h, q_ptr.ctypes.data, q_term.ctypes.data, q_w.ctypes.data, nq, k,
-                                1 if drop_df_eq_n else 0, int(threads), ords.ctypes.data, scores.ctypes.data,
-                                n.ctypes.data)
+        rc = lib().otaat_search_mode(self._h, q_ptr.ctypes.data, q_term.ctypes.data, q_w.ctypes.data, nq, k,
+                                     1 if drop_df_eq_n else 0, int(threads), self.MODES[mode], ords.ctypes.data,
+                                     scores.ctypes.data, n.ctypes.data)
         if rc != 0:
             raise OverflowError("otaat_search: score bound exceeds u32 or allocation failed")
         return ords, scores, n

@@ -52,6 +52,15 @@ try:
 except Exception:
     doc = {"_comment": "per-workload SUMS over all dispatches of a profiled bench command (rocprofv3 --pmc, one pass per "
                        "counter group); divide by `steps` for per-step figures. Written by scripts/prof_counters.py."}
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from mllm_sparse_retrieval_amd import _buildinfo  # noqa: E402
+
+# which binary these counters describe: bench.py withholds every counter-backed figure (`counters_stale`) when the
+# kernels of the tree it runs in hash differently
+stamp = _buildinfo.stamp()
+if doc.get("_stamp") and doc["_stamp"].get("kernel_source_sha256") != stamp["kernel_source_sha256"]:
+    sys.exit(f"{out_path} was started on other kernel sources: delete it and profile every workload again")
+doc["_stamp"] = stamp
 doc[workload] = {"steps": steps, "kernels": {k: dict(v) for k, v in sorted(kern.items()) if k.startswith("msr::")}}
 json.dump(doc, open(out_path, "w"), indent=1, sort_keys=True)
 print(f"{workload}: {len(doc[workload]['kernels'])} kernels -> {out_path}")

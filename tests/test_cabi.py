@@ -60,3 +60,23 @@ def test_product_never_imports_the_oracle():
             if fn.endswith((".py", ".cpp", ".hip", ".h")):
                 text = open(os.path.join(dirpath, fn), encoding="utf-8").read()
                 assert "oracle" not in text.replace("the oracle", "").replace("an oracle", "") or fn == "dist.py", fn
+
+
+def test_no_torch_gpu_call_in_the_search_or_bench_processes():
+    """libmsr.so brings /opt/rocm's HIP runtime into the process, torch ships an older one under the same sonames, and
+    whichever loads first serves both: torch's own GPU kernels do not run on the foreign runtime (round 2: 20 segfaults
+    under rocprofv3 from a torch device-to-device copy in bench.py, DESIGN.md §6 — not catchable by try/except). So the
+    package and the benchmark may only ever ask torch for the device COUNT (no GPU initialisation) and for the
+    synchronize() the bench contract names; everything else on the GPU goes through libmsr.so."""
+    allowed = {"device_count", "synchronize"}
+    files = [os.path.join(ROOT, "bench.py"), os.path.join(ROOT, "__graft_entry__.py")]
+    for dirpath, _, names in os.walk(os.path.join(ROOT, "mllm_sparse_retrieval_amd")):
+        files += [os.path.join(dirpath, n) for n in names if n.endswith(".py")]
+    for dirpath, _, names in os.walk(os.path.join(ROOT, "scripts")):
+        files += [os.path.join(dirpath, n) for n in names if n.endswith(".py")]
+    for fn in files:
+        text = open(fn, encoding="utf-8").read()
+        for call in re.findall(r"torch\.cuda\.([A-Za-z_]+)\s*\(", text):
+            assert call in allowed, f"{os.path.relpath(fn, ROOT)} calls torch.cuda.{call}()"
+        assert not re.search(r"\.(cuda|to)\(\s*['\"]?cuda", text), f"{os.path.relpath(fn, ROOT)} moves a tensor to the GPU through torch"
+        assert "device='cuda'" not in text and 'device="cuda"' not in text, os.path.relpath(fn, ROOT)

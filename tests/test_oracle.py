@@ -110,6 +110,26 @@ def test_three_restatements_agree(seed):
                 a = [(int(o1[0][i, j]), int(o1[1][i, j])) for j in range(int(o1[2][i]))]
                 assert a == o2[i]
             assert (o1[0] == o3[0]).all() and (o1[1] == o3[1]).all() and (o1[2] == o3[2]).all()
+            # the two other baseline rows of bench.py come from the same file and must return the same hits: TAAT over
+            # touched docs only, and document-at-a-time MaxScore pruning (ties at the k-th place included)
+            for mode in ("touched", "maxscore"):
+                o4 = ti.search(qp, qt, qw, k, drop_df_eq_n=drop, threads=2, mode=mode)
+                assert all((a == b).all() for a, b in zip(o3, o4)), (mode, drop, k)
+
+
+@pytest.mark.parametrize("n_docs,n_terms,nnz", [(9000, 7, 3), (4097, 300, 10), (1, 5, 2)])
+def test_pruning_baseline_equals_exhaustive(n_docs, n_terms, nnz):
+    """MaxScore over several 4096-doc windows: few terms (mass ties), a window boundary right after the last doc, a
+    single doc; weights that make some lists non-essential early (one heavy term, many light ones)."""
+    rng = np.random.default_rng(n_docs)
+    docs, (qp, qt, qw) = _random_case(rng, n_docs, n_terms, nnz, 30, 6)
+    qw = np.where(np.arange(len(qw)) % 6 == 0, qw * 50, qw).astype(np.int32)     # one dominant term per query
+    ti, _ = taat.TaatIndex.from_rows_by_docid(*docs, n_terms)
+    for k in (1, 10, 1000):
+        want = ti.search(qp, qt, qw, k)
+        for mode in ("touched", "maxscore"):
+            got = ti.search(qp, qt, qw, k, threads=4, mode=mode)
+            assert all((a == b).all() for a, b in zip(want, got)), (mode, k)
 
 
 @settings(max_examples=40, deadline=None)
