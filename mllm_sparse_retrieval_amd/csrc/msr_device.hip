@@ -1402,13 +1402,26 @@ static int termshard_emulated_impl(msr_index* const* hs, int n_shards, const int
             set_error("hipMalloc failed in msr_search_termshard_emulated");
             rc = MSR_E_NOMEM;
         }
+    // diagnostic (MSR_DEBUG_TERMSHARD): HIP-event time of every shard's dump and every logical rank's selection — the
+    // per-rank compute of the real protocol, which an 8-GPU run adds the reduce-scatter to (scripts/gpu_c4_termshard_probe.py)
+    static const bool dbg_ts = getenv("MSR_DEBUG_TERMSHARD") != nullptr;
+    std::vector<hipEvent_t> tev;
+    auto mark = [&]() {
+        if (!dbg_ts) return;
+        hipEvent_t e = nullptr;
+        if (hipEventCreate(&e) == hipSuccess) (void)hipEventRecord(e, d->stream);
+        tev.push_back(e);
+    };
+    int n_passes = 0;
     for (uint32_t q0 = 0; q0 < (uint32_t)nq && rc == MSR_OK; q0 += p.qt) {
         const uint32_t qn = std::min<uint32_t>(p.qt, (uint32_t)nq - q0);
+        ++n_passes;
         if (hipMemsetAsync(d_S, 0, (size_t)qn * p.range_elems * p.G * 4, d->stream) != hipSuccess) {
             set_error("hipMemsetAsync failed");
             rc = MSR_E_HIP;
             break;
         }
+        mark();
         for (int g = 0; g < n_shards && rc == MSR_OK; ++g) {
             ScoreArgs sa;
             fill_score_args(sa, bs[g], k);
@@ -1418,6 +1431,7 @@ static int termshard_emulated_impl(msr_index* const* hs, int n_shards, const int
             sa.tpr = p.tpr;
             sa.dump_add = 1;
             rc = launch_score(d->stream, h->tile_docs, 0, h->n_tiles, sa, true);
+            mark();
         }
         for (int r = 0; r < n_shards && rc == MSR_OK; ++r) {
             SelectArgs se;
@@ -1433,8 +1447,29 @@ static int termshard_emulated_impl(msr_index* const* hs, int n_shards, const int
             se.qn = qn;
             se.k = (uint32_t)k;
             rc = launch_select(d->stream, h->tile_docs, se);
+            mark();
         }
     }
+    if (dbg_ts && rc == MSR_OK && hipStreamSynchronize(d->stream) == hipSuccess) {
+        // per pass: 1 + n_shards + n_shards marks
+        std::vector<double> dump_ms((size_t)n_shards, 0.0), sel_ms((size_t)n_shards, 0.0);
+        const size_t per = 1 + 2 * (size_t)n_shards;
+        for (int ps = 0; ps < n_passes; ++ps)
+            for (int i = 0; i < 2 * n_shards; ++i) {
+                hipEvent_t a = tev[(size_t)ps * per + (size_t)i], b2 = tev[(size_t)ps * per + (size_t)i + 1];
+                float ms = 0;
+                if (a && b2) (void)hipEventElapsedTime(&ms, a, b2);
+                (i < n_shards ? dump_ms[(size_t)i] : sel_ms[(size_t)(i - n_shards)]) += ms;
+            }
+        fprintf(stderr, "[msr] term shards G=%d, %d queries in %d passes of <= %u (send buffer %.2f GB per pass): dump ms per shard [",
+                n_shards, nq, n_passes, p.qt, (double)p.qt * (double)p.range_elems * p.G * 4 / 1e9);
+        for (int g = 0; g < n_shards; ++g) fprintf(stderr, "%s%.2f", g ? ", " : "", dump_ms[(size_t)g]);
+        fprintf(stderr, "] (on this one GPU a dump ADDS to the shared buffer: read + write), select ms per doc range [");
+        for (int r = 0; r < n_shards; ++r) fprintf(stderr, "%s%.2f", r ? ", " : "", sel_ms[(size_t)r]);
+        fprintf(stderr, "]\n");
+    }
+    for (hipEvent_t e : tev)
+        if (e) (void)hipEventDestroy(e);
     for (int r = 0; r < n_shards && rc == MSR_OK; ++r) {
         MergeArgs ma;
         ma.lists = rank_part[r];

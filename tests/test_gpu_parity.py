@@ -468,6 +468,25 @@ def test_full_size_properties_c4(m, tmp_path, tile_docs, n_tiles):
         mo, _, mu, mn = ix.merge_lists(np.stack([l[0] for l in lists]), np.stack([l[2] for l in lists]),
                                        np.stack([l[3] for l in lists]), 10)
         assert (mo == o).all() and (mu == u).all() and (mn == n).all()
+    if tile_docs == 0:
+        # the north star's TERM-range partition at config-4 size (BASELINE.json configs[3]): G = 8 handles,
+        # each resident with its own term range of all 123 tiles only, play the exact protocol on this one GPU — every
+        # shard dumps its partial accumulator tiles (two passes of 1 024 queries through the 4 GiB buffer), the sums of
+        # each doc range are selected (16 tiles per range), the range lists merged: identical to the doc-range result
+        from mllm_sparse_retrieval_amd.index import search_termshard_emulated_handles
+
+        shards = [m.SparseIndex(path, device=0, term_shard=(g, 8)) for g in range(8)]
+        try:
+            assert [sh.term_lo for sh in shards[1:]] == [sh.term_hi for sh in shards[:-1]]
+            assert shards[0].term_lo == 0 and shards[-1].term_hi == n_terms
+            whole = sum(sh.resident_bytes for sh in shards)
+            with m.SparseIndex(path, device=0) as full:
+                assert whole < 1.25 * full.resident_bytes          # nothing replicated but shared dense-head pairs
+            to, tf, tu, tn = search_termshard_emulated_handles(shards, qp, qt, qw, 10)
+            assert (to == o).all() and (tu == u).all() and (tf == f).all() and (tn == n).all()
+        finally:
+            for sh in shards:
+                sh.close()
     # oracle on a sample of the same queries
     oix, _ = helpers.taat_oracle(docs, n_terms)
     s = 200
