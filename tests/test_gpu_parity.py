@@ -374,6 +374,104 @@ def test_cli_search_end_to_end(m, tmp_path, capsys):
         assert all(x == y or abs(db[x] - db[y]) <= 2e-6 for x, y in zip(ra, rb))
 
 
+@pytest.mark.parametrize("query_type", ["image", "text"])
+def test_cli_on_the_reference_coco_ids(m, tmp_path, capsys, query_type):
+    """index -> search --qrels -> eval on a synthetic corpus KEYED TO THE IDS OF THE REFERENCE'S COCO-5K TEST SPLIT
+    (tests/golden/coco_test_ids.csv = the id columns of data/coco/coco_test.csv): docs are named by real caption ids (2-6
+    digits: ordinals follow the id STRING order, contract T1) or real image ids (sparse, 0 .. 40 503), image queries have
+    5 or 6 target captions (any-of-N get_target, src/dataset.py:164-168, src/metrices.py:76-84), and 149 ids exist on both
+    sides, so --remove_query (scripts/search_sparse.sh:26) removes real docs. The TREC run must equal the oracle's hits
+    under those ids, and the printed recall an independent count."""
+    import json
+
+    from mllm_sparse_retrieval_amd import cli
+    from mllm_sparse_retrieval_amd.fusion import read_trec_run
+    from mllm_sparse_retrieval_amd.qrels import CrossModalQrels
+
+    ds = CrossModalQrels(os.path.join(os.path.dirname(__file__), "golden", "coco_test_ids.csv"), "coco")
+    assert len(ds.img_id_list) == 5000 and len(ds.text_id_list) == 25010
+    assert sorted(len(v) for v in ds.img2text.values())[-10:] == [6] * 10 and len(set(ds.img_id_list) & set(ds.text_id_list)) == 149
+    n_terms, k = 3000, 10
+    if query_type == "image":   # image -> text: docs = captions, queries = images
+        doc_ids, query_ids = ds.text_id_list, ds.img_id_list[:1500]
+        owner = {t: i for i, ts in ds.img2text.items() for t in ts}
+        pair_of_doc = [owner[d] for d in doc_ids]
+    else:                       # text -> image: docs = images, queries = captions
+        doc_ids, query_ids = ds.img_id_list, ds.text_id_list[:3000]
+        pair_of_doc = doc_ids
+    # synthetic vectors with planted signal: a caption and its image share 8 terms; tokens are 't<id>'
+    img_index = {i: j for j, i in enumerate(ds.img_id_list)}
+    base = m.synth_vectors(5000, 8, n_terms, seed=77, threads=8)                # the shared terms of every image
+    bt, bw = base[1].reshape(5000, 8), base[2].reshape(5000, 8)
+    fill_d = m.synth_vectors(len(doc_ids), 24, n_terms, seed=78, threads=8)
+    fill_q = m.synth_vectors(len(query_ids), 8, n_terms, seed=79, threads=8)
+    enc = tmp_path / "enc"
+    enc.mkdir()
+    doc_rows = []
+    with open(enc / "corpus_0.jsonl", "w") as f:
+        for j, d in enumerate(doc_ids):
+            img = img_index[pair_of_doc[j]]
+            vec = {f"t{int(t)}": int(w) for t, w in zip(fill_d[1][24 * j:24 * j + 24], fill_d[2][24 * j:24 * j + 24])}
+            vec.update({f"t{int(t)}": int(w) for t, w in zip(bt[img], bw[img])})
+            if query_type == "image" and d in img_index:
+                # this caption's id is ALSO an image id: let it match that image's query too, so that the query finds
+                # "itself" among its hits and --remove_query has a real doc to remove
+                vec.update({f"t{int(t)}": int(w) + 50 for t, w in zip(bt[img_index[d]], bw[img_index[d]])})
+            doc_rows.append(vec)
+            f.write(json.dumps(dict(id=d, content="", vector=vec)) + "\n")
+    q_rows = []
+    with open(enc / "query.tsv", "w") as f:
+        for j, qid in enumerate(query_ids):
+            img = img_index[qid if query_type == "image" else ds.text2img[qid]]
+            vec = {f"t{int(t)}": int(w) for t, w in zip(fill_q[1][8 * j:8 * j + 8], fill_q[2][8 * j:8 * j + 8])}
+            vec.update({f"t{int(t)}": int(w) for t, w in zip(bt[img], bw[img])})
+            q_rows.append(vec)
+            f.write(qid + "\t" + " ".join(" ".join([tok] * w) for tok, w in vec.items()) + "\n")
+    qrels = os.path.join(os.path.dirname(__file__), "golden", "coco_test_ids.csv")
+    cli.main(["index", "--input", str(enc), "--threads", "8"])
+    cli.main(["search", "--sparse_index", str(enc), "--depth", str(k), "--batch_size", "512", "--query_type", query_type,
+              "--dataset_name", "coco", "--qrels", qrels, "--save_dir", str(tmp_path / "runs"), "--remove_query"])
+    out = capsys.readouterr().out
+    line = [l for l in out.splitlines() if l.startswith("Sparse reps recall")][0]
+    printed = [float(x.split()[1].rstrip(",")) for x in line.split("r@")[1:]][:3]      # r@1, r@5, r@10
+    run = read_trec_run(str(tmp_path / "runs" / "sparse.trec"))
+    # the oracle under the same ids (ordinals = ranks of the id STRINGS)
+    vocab = sorted({t for v in doc_rows for t in v})
+    tid = {t: i for i, t in enumerate(vocab)}
+    dp = np.concatenate([[0], np.cumsum([len(v) for v in doc_rows])]).astype(np.uint64)
+    dt = np.array([tid[t] for v in doc_rows for t in v], dtype=np.uint32)
+    dw = np.array([w for v in doc_rows for w in v.values()], dtype=np.uint32)
+    oix, order = helpers.taat_oracle((dp, dt, dw), len(vocab), doc_ids)
+    sorted_ids = [doc_ids[r] for r in order]
+    assert sorted_ids == sorted(doc_ids, key=lambda x: x.encode()) and sorted_ids != sorted(doc_ids, key=int)
+    qp = np.concatenate([[0], np.cumsum([len(v) for v in q_rows])]).astype(np.int64)
+    qt = np.array([tid.get(t, -1) for v in q_rows for t in v], dtype=np.int32)
+    qw = np.array([w for v in q_rows for w in v.values()], dtype=np.int32)
+    wo, ws, wn = oix.search(qp, qt, qw, k, threads=8)
+    hits = {1: 0, 5: 0, 10: 0}
+    removed = 0
+    for j, qid in enumerate(query_ids):
+        want = [(sorted_ids[int(o)], float(s)) for o, s in zip(wo[j, :wn[j]], ws[j, :wn[j]])]
+        removed += any(d == qid for d, _ in want)
+        want = [(d, s) for d, s in want if d != qid]                                   # remove_query, src/search.py:72-74
+        got = list(run[qid]["docs"].items())
+        assert got == want, (qid, got[:3], want[:3])
+        target = ds.get_target(qid, query_type)
+        tset = set(target) if isinstance(target, list) else {target}
+        ranked = [d for d, _ in sorted(want, key=lambda kv: -kv[1])]                    # (stable: ties keep hit order)
+        for kk in hits:
+            hits[kk] += bool(tset & set(ranked[:kk]))
+    assert printed == pytest.approx([hits[kk] / len(query_ids) for kk in (1, 5, 10)], abs=1e-12)
+    assert printed[2] > 0.5                                                             # the planted signal is found
+    if query_type == "image":
+        assert removed > 0                                                             # a real id lives on both sides
+    # the stand-alone recall reporter over the TREC run gives the same numbers
+    cli.main(["eval", "--runs_dir", str(tmp_path / "runs"), "--qrels", qrels, "--dataset_name", "coco", "--query_type",
+              query_type, "--queries", str(enc / "query.tsv")])
+    line2 = [l for l in capsys.readouterr().out.splitlines() if l.startswith("Sparse reps recall")][0]
+    assert line2 == line
+
+
 def _free_port():
     import socket
 
