@@ -233,7 +233,8 @@ void msr_dense_close(msr_dense* dx);
  * one shape allocate nothing (the reference searches in batches of 2, scripts/search.sh:29). */
 int msr_dense_stats(const msr_dense* dx, uint64_t out[4]);
 /* Host helper for the two calls above: n f32 values -> IEEE fp16, round to nearest even (what numpy's astype(float16)
- * and the reference's .half() produce: src/search.py:257), on `threads` host threads (<= 0: all). The reference hands
+ * and the reference's .half() produce: src/search.py:257; bit-identical for every non-NaN input — a NaN comes out
+ * quiet, numpy keeps its payload), on `threads` host threads (<= 0: all). The reference hands
  * its query matrix over in f32 (src/search.py:342-343); converting 25 010 x 4 096 values in numpy takes longer than
  * the whole GPU search. */
 int msr_f32_to_f16(const float* src, uint16_t* dst, uint64_t n, int threads);
@@ -241,11 +242,21 @@ int msr_f32_to_f16(const float* src, uint16_t* dst, uint64_t n, int threads);
 /* ---- hybrid search on the GPU: sparse top-`depth` + dense top-`depth` + the reference's min-max fusion
  * (fuse, src/hybrid.py:32-53, weights [alpha, 1-alpha] src/search.py:459) + top-k, without leaving HBM in between.
  * row2ord[r] = sparse doc ordinal of dense row r; self_ord[q] (nullable) = ordinal removed from query q's lists
- * (remove_query, src/search.py:72-74) or -1. ms (nullable) = {sparse, dense GEMM, dense select, fusion} kernel ms.
- * Single-tile indexes (n_docs <= 8192) with k <= 64 take the fused path: the GEMM runs on the passage rows permuted into
- * ordinal order, and ONE kernel per query does sparse scoring + both depth selections + fusion + top-k; ms is then
- * {that kernel, dense GEMM, 0, 0}, and a tie in the DENSE score at the depth boundary goes to the lower doc ordinal
- * (the list-based path: to the lower row index). row2ord must be a permutation of the ordinals. */
+ * (remove_query, src/search.py:72-74) or -1. row2ord must be a permutation of the ordinals. depth, k <= MSR_KMAX.
+ * The GEMM runs on the passage rows permuted into ordinal order (built once per mapping, kept on the dense handle), so a
+ * query's row of dense scores lines up with the sparse accumulator tiles, and no list ever leaves HBM:
+ *   - one tile (n_docs <= 8192), k <= 64: ONE kernel per query does sparse scoring, both depth selections, fusion and
+ *     top-k (hybrid_tiles); ms = {that kernel, dense GEMM, 0, 0};
+ *   - otherwise (the reference's own hybrid run: 25 010 caption docs = 4 tiles, scripts/search.sh): one workgroup per
+ *     (tile, query) scores the tile and emits its quota of candidates for both depth lists, one workgroup per query
+ *     finds both depth-th bests among them, fuses and ranks; a query whose depth list a tile's quota did not cover
+ *     (verified per query) is repeated with every tile's own top-depth, so the result is exact whatever the quota;
+ *     ms = {candidate kernel, dense GEMM, 0, fusion kernel};
+ *   - tile sizes other than 4096 / 8192 docs, shard handles, MSR_NO_FUSED_HYBRID: the list-based path (score_tiles at
+ *     k = depth, select_tiles over the score matrix, fuse_tiles, merges); ms = {sparse, dense GEMM, dense select, fusion}.
+ * Tie rule of the DENSE depth list (two passages with bit-equal scores at the depth boundary — duplicated captions do
+ * that): the first two paths keep the lower doc ORDINAL, the list-based path and msr_dense_search the lower ROW, as a
+ * flat index does. Everything else (sparse ties, fused-score ties: lower ordinal) is the same on every path. */
 int msr_hybrid_search(msr_index* ix, msr_dense* dx, const int64_t* q_ptr, const int32_t* q_term, const int32_t* q_w,
                       const uint16_t* q_fp16, int nq, int depth, int k, float alpha, uint32_t flags,
                       const uint32_t* row2ord, const int32_t* self_ord, uint32_t* out_ord, float* out_score, int32_t* out_n,

@@ -28,7 +28,9 @@ def keys_to_f32(keys):
 def _as_fp16_rows(x, dim=None, holder=None):
     """[rows, dim] matrix -> C-contiguous fp16 (round to nearest even), columns padded to a multiple of 32.
     `holder`: an object whose `_q16` attribute keeps the output buffer between calls (a fresh 200 MB array costs more in
-    page faults than the conversion itself)."""
+    page faults than the conversion itself) — which makes the holder single-threaded, see DenseIndex.
+    msr_f32_to_f16 rounds like numpy's astype(float16) for every non-NaN value (NaN payloads differ: F16C sets the
+    quiet bit, numpy keeps the payload)."""
     x = np.asarray(x)
     if x.ndim != 2:
         raise ValueError("expected a [rows, dim] matrix")
@@ -52,7 +54,11 @@ def _as_fp16_rows(x, dim=None, holder=None):
 
 
 class DenseIndex:
-    """fp16 passage matrix resident in HBM."""
+    """fp16 passage matrix resident in HBM.
+
+    NOT thread-safe per handle (like every libmsr handle: one in-flight call per handle): the fp16 copy of the query
+    matrix, the device scratch and the HIP stream all live on the handle and are reused by the next call. Threads that
+    search concurrently each open their own DenseIndex."""
 
     def __init__(self, p_reps, device=0):
         p16 = _as_fp16_rows(p_reps)

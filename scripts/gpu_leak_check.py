@@ -39,7 +39,10 @@ def main():
             ix.search_csr(qp, qt, qw, 100)
             dix = DenseIndex(p)
             dix.search(q, 10)
-            hybrid_search(ix, dix, qp, qt, qw, q, 100, 10, 0.5, row_to_ordinal(ix, ids))
+            r2o = row_to_ordinal(ix, ids)
+            hybrid_search(ix, dix, qp, qt, qw, q, 100, 10, 0.5, r2o)     # one tile, k <= 64: the fused kernel
+            hybrid_search(ix, dix, qp, qt, qw, q, 100, 100, 0.5, r2o)    # k > 64: candidate kernels + per-query fusion
+            ix.search_csr(qp[:5], qt[: qp[4]], qw[: qp[4]], 10)          # a small call: mapped host blocks
             dix.close()
             # (b is left to the index: closing the index detaches live batches)
     for _ in range(20):  # warm rounds: the runtime's own pools and code objects reach their steady size
