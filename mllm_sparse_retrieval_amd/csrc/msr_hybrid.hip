@@ -383,7 +383,7 @@ struct msr_dense {
     bool lds_attr_set = false;  // dense_scores_256 needs the 128 KiB dynamic-LDS opt-in once per device
     // device scratch of the fused hybrid call (query matrix, score rows, result lists), kept between calls and only ever
     // grown: six hipMalloc / hipFree pairs of up to 200 MB cost a call more than its kernels
-    enum Slot { S_Q = 0, S_S, S_ORD, S_SF, S_N, S_SELF, S_CS, S_CD, S_META, S_FLAGS, S_QLIST, S_PART, S_SU, S_COUNT };
+    enum Slot { S_Q = 0, S_S, S_ORD, S_SF, S_N, S_SELF, S_CS, S_META, S_FLAGS, S_QLIST, S_PART, S_SU, S_COUNT };
     void* scratch[S_COUNT] = {};
     size_t scratch_bytes[S_COUNT] = {};
     uint64_t n_device_allocs = 0;  // hipMalloc calls made on behalf of this handle (steady-state calls make none)
@@ -804,15 +804,19 @@ struct HybridArgs {
     int32_t* out_n;           // [nq]
     // ---- multi-tile indexes (MODE 1 of hybrid_tiles + hybrid_fuse_query): per (launch row, tile) candidate lists
     const uint32_t* qlist;    // launch row -> query of the batch (second round: the flagged queries), or null: q0 + row
-    uint64_t* cand_s;         // [rows][n_tiles][stride] sparse candidates  score << 32 | ~ordinal  (0 = empty slot)
-    uint64_t* cand_d;         // [rows][n_tiles][stride] dense candidates   f32 key << 32 | ~ordinal
+    // candidate RECORDS, [rows][n_tiles][stride] each: a doc that is a candidate for either depth list of its tile, with
+    // its sparse score (0: not a sparse candidate) and the key of its dense score (0: not a dense candidate)
+    uint32_t* rec_ord;        // doc ordinal (0xFFFFFFFF = empty slot)
+    uint32_t* rec_s;
+    uint32_t* rec_d;
     uint4* tile_meta;         // [rows][n_tiles][2]: {weakest emitted sparse composite (lo, hi), present sparse scores, all
                               //   emitted?}, {weakest emitted dense composite (lo, hi), docs of the tile, all emitted?}
     uint32_t n_tiles;         // tiles of the index
-    uint32_t stride;          // candidate slots per (row, tile, side)
-    uint32_t quota_full;      // candidates a full tile emits per side, <= stride
+    uint32_t stride;          // record slots per (row, tile): 2 x quota_full (the union of two candidate sets)
+    uint32_t quota_full;      // candidates a full tile emits per side
     uint32_t quota_last;      // ... and the (shorter) last tile
     uint32_t* flags;          // [nq] hybrid_fuse_query: 1 = the candidate lists did not cover a depth list (second round)
+    unsigned long long* fq_stamps = nullptr;  // diagnostic (MSR_DEBUG_HYBRID): phase clocks of hybrid_fuse_query
 };
 
 // The rare paths of hybrid_tiles, kept OUT OF LINE: inlined, the general selections' live ranges cost the common path
@@ -1111,13 +1115,15 @@ __global__ __launch_bounds__(NT, MIN_WAVES) void hybrid_tiles(const ScoreArgs a,
     stamp(1);
     if constexpr (MODE == 1) {
         // ---- the tile's candidates: every element at or above its side's threshold composite (exactly need_s / need_d
-        // of them: composites are unique), as GLOBAL composites  score or f32 key << 32 | ~ordinal, in any order
+        // of them: composites are unique) becomes ONE record {ordinal, sparse score or 0, dense key or 0} — a doc that
+        // is a candidate on both sides arrives at hybrid_fuse_query already joined
         __syncthreads();  // (everyone has read ds.ncand / ds.T of the selection)
         if (tid < 2) ds.ncand[tid] = 0;
         __syncthreads();
         const uint64_t slot0 = ((uint64_t)blockIdx.x * h.n_tiles + tile_l) * h.stride;
-        uint64_t* const cs = h.cand_s + slot0;
-        uint64_t* const cd = h.cand_d + slot0;
+        uint32_t* const ro = h.rec_ord + slot0;
+        uint32_t* const rs = h.rec_s + slot0;
+        uint32_t* const rd = h.rec_d + slot0;
         const uint32_t ts_key = (uint32_t)(T_s >> 13), ts_inv = (uint32_t)T_s & 8191u;
         const uint32_t td_inv = (uint32_t)T_d & 8191u;
         const float td_f = key_to_f32((uint32_t)(T_d >> 13)) + 0.0f;
@@ -1130,23 +1136,26 @@ __global__ __launch_bounds__(NT, MIN_WAVES) void hybrid_tiles(const ScoreArgs a,
                 for (int e = 0; e < 4; ++e) {
                     const uint32_t local = 4u * ((uint32_t)r * NT + tid) + (uint32_t)e;
                     const uint32_t inv = (uint32_t)(TILE_DOCS - 1) - local;
-                    const uint32_t nord = 0xFFFFFFFFu - (uint32_t)(doc0 + local);
                     const float d = df[4 * r + e];
-                    if (need_s && s4[e] != 0 && (s4[e] > ts_key || (s4[e] == ts_key && inv >= ts_inv))) {
+                    const bool is_s = need_s && s4[e] != 0 && (s4[e] > ts_key || (s4[e] == ts_key && inv >= ts_inv));
+                    const bool is_d = d > td_f || (d == td_f && inv >= td_inv);  // (NaN = past the corpus: never)
+                    if (is_s || is_d) {
                         const uint32_t pos = atomicAdd(&ds.ncand[0], 1u);
-                        if (pos < h.stride) cs[pos] = ((uint64_t)s4[e] << 32) | nord;
-                    }
-                    if (d > td_f || (d == td_f && inv >= td_inv)) {  // (NaN = past the corpus: never)
-                        const uint32_t pos = atomicAdd(&ds.ncand[1], 1u);
-                        if (pos < h.stride) cd[pos] = ((uint64_t)f32_to_key(d) << 32) | nord;
+                        if (pos < h.stride) {
+                            ro[pos] = (uint32_t)(doc0 + local);
+                            rs[pos] = is_s ? s4[e] : 0u;
+                            rd[pos] = is_d ? f32_to_key(d) : 0u;
+                        }
                     }
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
         __syncthreads();
-        const uint32_t got_s = min(ds.ncand[0], h.stride), got_d = min(ds.ncand[1], h.stride);
-        for (uint32_t i = got_s + tid; i < h.stride; i += NT) cs[i] = 0ull;  // empty slots
-        for (uint32_t i = got_d + tid; i < h.stride; i += NT) cd[i] = 0ull;
+        for (uint32_t i = min(ds.ncand[0], h.stride) + tid; i < h.stride; i += NT) {  // empty slots
+            ro[i] = 0xFFFFFFFFu;
+            rs[i] = 0u;
+            rd[i] = 0u;
+        }
         if (tid == 0) {
             // weakest emitted element of each side as a global composite; "all emitted" = the list holds everything the
             // tile has (no threshold to respect)
@@ -1435,31 +1444,50 @@ __device__ __forceinline__ uint64_t kth_largest_u64(Each each, uint32_t need, Kt
     }
 }
 
-// Multi-tile indexes, second kernel: ONE workgroup per query finishes what hybrid_tiles<MODE 1> prepared — the depth-th
-// best of each side among the tiles' candidates (exact when every tile's weakest candidate lies at or below it: checked,
-// else the query is flagged for the second round), the reference's fusion over the union of the two lists
+// Multi-tile indexes, second kernel: ONE workgroup per query finishes what hybrid_tiles<MODE 1> prepared. The query's
+// candidate records (a few thousand: 4 tiles x 836 at the reference's own shape) live in REGISTERS from the first load to
+// the last pass: the depth-th best of each side among them (exact when every tile's weakest candidate lies at or below
+// it: checked, else the query is flagged for the second round), the reference's fusion over the union of the two lists
 // (src/hybrid.py:32-53: min = the depth-th score, max = the best, of the UNFILTERED lists, src/search.py:76-81; the
-// query's own doc skipped, src/search.py:72-74) in an LDS hash table keyed by doc ordinal, and the top-k of the fused
-// scores (ties: lower ordinal). k <= 1024, depth <= 1024.
-constexpr int kFuseSlots = 4096;  // >= 2 x the 2 x 1024 members a union can hold
-
-template <int NT>
+// query's own doc skipped, src/search.py:72-74) — a record carries both of its doc's scores, so there is nothing to
+// join — and the top-k of the fused scores (ties: lower ordinal). k <= 1024, depth <= 1024.
+template <int NT, int EPT /* records per thread held in registers */>
 __global__ __launch_bounds__(NT) void hybrid_fuse_query(const HybridArgs h, const uint32_t q0) {
     static_assert(NT >= 256 && NT % 64 == 0 && NT / 64 <= 16, "scratch layout");
-    __shared__ uint32_t hkey[kFuseSlots];   // doc ordinal + 1 (0 = free)
-    __shared__ float hval[kFuseSlots];      // fused score
     __shared__ __attribute__((aligned(16))) uint64_t cand[kCandCap];
+    __shared__ __attribute__((aligned(16))) uint64_t res[kCandCap];
     __shared__ __attribute__((aligned(16))) KthScratch ks;
-    __shared__ uint32_t red[4];             // present sparse scores, docs, invalid flag, members
+    __shared__ uint32_t red[4];             // present sparse scores, docs, invalid flag, collected keys
     const uint32_t tid = threadIdx.x, lane = tid & 63;
     const uint32_t row = blockIdx.x;
     const uint32_t q = h.qlist ? h.qlist[row] : q0 + row;
     const uint32_t n_slots = h.n_tiles * h.stride;
-    const uint64_t* const cs = h.cand_s + (uint64_t)row * n_slots;
-    const uint64_t* const cd = h.cand_d + (uint64_t)row * n_slots;
+    const uint32_t* const g_ord = h.rec_ord + (uint64_t)row * n_slots;
+    const uint32_t* const g_s = h.rec_s + (uint64_t)row * n_slots;
+    const uint32_t* const g_d = h.rec_d + (uint64_t)row * n_slots;
     const uint4* const meta = h.tile_meta + (uint64_t)row * h.n_tiles * 2;
+    long long t_prev = h.fq_stamps ? clock64() : 0;
+    auto stamp = [&](int slot) {  // thread 0 of one workgroup in 16 adds its clock deltas per phase
+        if (h.fq_stamps && tid == 0 && (blockIdx.x & 15u) == 0) {
+            const long long now = clock64();
+            atomicAdd(&h.fq_stamps[slot], (unsigned long long)(now - t_prev));
+            t_prev = now;
+        }
+    };
+    // Read in a loop from global memory, every pass below would pay a dependent L2 round trip per element (measured with
+    // the first version of this kernel: 0.47 ms instead of 0.3 for 5 000 queries); queries with more records than the
+    // registers hold (second round on many tiles) take that loop.
+    const bool in_regs = n_slots <= (uint32_t)(EPT * NT);  // (uniform)
+    uint32_t ro[EPT], rs[EPT], rd[EPT];
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) {
+        const uint32_t i = tid + (uint32_t)e * NT;
+        const bool live = in_regs && i < n_slots;
+        ro[e] = live ? g_ord[i] : 0xFFFFFFFFu;
+        rs[e] = live ? g_s[i] : 0u;
+        rd[e] = live ? g_d[i] : 0u;
+    }
     if (tid < 4) red[tid] = 0;
-    for (uint32_t i = tid; i < kFuseSlots; i += NT) hkey[i] = 0;
     __syncthreads();
     {
         uint32_t ns = 0, nd = 0;
@@ -1476,39 +1504,25 @@ __global__ __launch_bounds__(NT) void hybrid_fuse_query(const HybridArgs h, cons
     }
     __syncthreads();
     const uint32_t need_s = min(h.depth, red[0]), need_d = min(h.depth, red[1]);
-    // The query's candidates live in REGISTERS when they fit (EPT per thread and side: 4 tiles x 418 of the reference's
-    // own shape are 1 672 per side): all loads are issued back to back, once. Read in a loop from global memory, every
-    // pass below pays a dependent L2 round trip per element (measured: 0.47 ms instead of 0.2 for 5 000 queries).
-    constexpr int EPT = 8;
-    const bool in_regs = n_slots <= (uint32_t)(EPT * NT);  // (uniform)
-    uint64_t rs[EPT], rd[EPT];
-#pragma unroll
-    for (int e = 0; e < EPT; ++e) {
-        const uint32_t i = tid + (uint32_t)e * NT;
-        const bool live = in_regs && i < n_slots;
-        rs[e] = live ? cs[i] : 0ull;
-        rd[e] = live ? cd[i] : 0ull;
-    }
-    auto each_s = [&](auto f) {
+    // visit(f): f(ordinal, sparse score, dense key) for every record of this thread
+    auto visit = [&](auto f) {
         if (in_regs) {
 #pragma unroll
-            for (int e = 0; e < EPT; ++e) f(rs[e]);
+            for (int e = 0; e < EPT; ++e) f(ro[e], rs[e], rd[e]);
         } else {
-            for (uint32_t i = tid; i < n_slots; i += NT) f(cs[i]);
+            for (uint32_t i = tid; i < n_slots; i += NT) f(g_ord[i], g_s[i], g_d[i]);
         }
     };
-    auto each_d = [&](auto f) {
-        if (in_regs) {
-#pragma unroll
-            for (int e = 0; e < EPT; ++e) f(rd[e]);
-        } else {
-            for (uint32_t i = tid; i < n_slots; i += NT) f(cd[i]);
-        }
-    };
+    auto comp = [](uint32_t v, uint32_t ord) -> uint64_t { return v ? ((uint64_t)v << 32) | (uint64_t)(0xFFFFFFFFu - ord) : 0ull; };
+    auto each_s = [&](auto f) { visit([&](uint32_t o, uint32_t sv, uint32_t) { f(comp(sv, o)); }); };
+    auto each_d = [&](auto f) { visit([&](uint32_t o, uint32_t, uint32_t dv) { f(comp(dv, o)); }); };
     uint32_t c_s, c_d;
     uint64_t mx_s, mx_d;
+    stamp(0);
     const uint64_t T_s = kth_largest_u64<NT>(each_s, need_s, ks, tid, &c_s, &mx_s);
+    stamp(1);
     const uint64_t T_d = kth_largest_u64<NT>(each_d, need_d, ks, tid, &c_d, &mx_d);
+    stamp(2);
     // ---- are the lists complete? a tile that did not emit everything it has must have its weakest candidate at or
     // below the side's depth-th best
     {
@@ -1528,7 +1542,8 @@ __global__ __launch_bounds__(NT) void hybrid_fuse_query(const HybridArgs h, cons
         }
         return;
     }
-    // ---- fusion: dense members first (the reference adds the dense term first: runs = [dense, sparse], src/search.py:459)
+    stamp(3);
+    // ---- fusion (src/hybrid.py:32-53; the dense term first: runs = [dense, sparse], src/search.py:459)
     const uint32_t self = h.self_ord ? (uint32_t)h.self_ord[q] : 0xFFFFFFFFu;
     const uint32_t smax_u = (uint32_t)(mx_s >> 32), smin_u = need_s ? (uint32_t)(T_s >> 32) : 0u;
     const float smax = need_s ? (float)smax_u : 0.f, smin = (float)smin_u;
@@ -1536,63 +1551,43 @@ __global__ __launch_bounds__(NT) void hybrid_fuse_query(const HybridArgs h, cons
     const float dmin = need_d ? key_to_f32((uint32_t)(T_d >> 32)) + 0.0f : 0.f;
     const float inv_sden = 1.0f / fmaxf(smax - smin, 1e-9f), inv_dden = 1.0f / fmaxf(dmax - dmin, 1e-9f);
     const bool spread_s = smax > smin, spread_d = dmax > dmin;
-    auto slot_of = [](uint32_t ord) { return (ord * 2654435761u) >> 20; };  // 12 bits
-    if (need_d)
-        each_d([&](const uint64_t key) {
-            if (!key || key < T_d) return;
-            const uint32_t ord = 0xFFFFFFFFu - (uint32_t)key;
-            if (ord == self) return;
-            const float d = key_to_f32((uint32_t)(key >> 32)) + 0.0f;
-            // (EXACTLY 1 at the maximum, as the reference's quotient is: see hybrid_tiles)
-            const float v = 0.f + h.w_dense * ((d == dmax && spread_d) ? 1.0f : (d - dmin) * inv_dden);
-            uint32_t sl = slot_of(ord);
-            while (atomicCAS(&hkey[sl], 0u, ord + 1u) != 0u) sl = (sl + 1u) & (kFuseSlots - 1);  // (dense docs are unique)
-            hval[sl] = v;
-        });
-    __syncthreads();
-    if (need_s)
-        each_s([&](const uint64_t key) {
-            if (!key || key < T_s) return;
-            const uint32_t ord = 0xFFFFFFFFu - (uint32_t)key;
-            if (ord == self) return;
-            const uint32_t sc = (uint32_t)(key >> 32);
-            const float v = h.w_sparse * ((sc == smax_u && spread_s) ? 1.0f : ((float)sc - smin) * inv_sden);
-            uint32_t sl = slot_of(ord);
-            for (;;) {
-                const uint32_t old = atomicCAS(&hkey[sl], 0u, ord + 1u);
-                if (old == 0u) {          // not in the dense list: a fresh entry (sparse docs are unique: no other writer)
-                    hval[sl] = 0.f + v;
-                    break;
-                }
-                if (old == ord + 1u) {    // in the dense list as well (inserted before the barrier): add the sparse term
-                    hval[sl] += v;
-                    break;
-                }
-                sl = (sl + 1u) & (kFuseSlots - 1);
-            }
-        });
-    __syncthreads();
-    // ---- top-k of the fused scores over the union (ties: lower ordinal)
-    auto fused_key = [&](uint32_t i) -> uint64_t {
-        const uint32_t kk = hkey[i];
-        return kk ? ((uint64_t)f32_to_key(hval[i]) << 32) | (uint64_t)(0xFFFFFFFFu - (kk - 1u)) : 0ull;
+    auto fused_key = [&](uint32_t o, uint32_t sv, uint32_t dv) -> uint64_t {
+        const bool in_s = need_s && sv && comp(sv, o) >= T_s;
+        const bool in_d = need_d && dv && comp(dv, o) >= T_d;
+        if (!(in_s || in_d) || o == self) return 0ull;
+        float f = 0.f;
+        if (in_d) {  // (EXACTLY 1 at the maximum, as the reference's quotient is: see hybrid_tiles)
+            const float d = key_to_f32(dv) + 0.0f;
+            f += h.w_dense * ((d == dmax && spread_d) ? 1.0f : (d - dmin) * inv_dden);
+        }
+        if (in_s) f += h.w_sparse * ((sv == smax_u && spread_s) ? 1.0f : ((float)sv - smin) * inv_sden);
+        return ((uint64_t)f32_to_key(f) << 32) | (uint64_t)(0xFFFFFFFFu - o);
     };
+    // the fused keys replace the records in the registers (16 x u64 for 48 x u32)
+    uint64_t fk[EPT];
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) fk[e] = in_regs ? fused_key(ro[e], rs[e], rd[e]) : 0ull;
+    auto each_f = [&](auto f) {
+        if (in_regs) {
+#pragma unroll
+            for (int e = 0; e < EPT; ++e) f(fk[e]);
+        } else {
+            for (uint32_t i = tid; i < n_slots; i += NT) f(fused_key(g_ord[i], g_s[i], g_d[i]));
+        }
+    };
+    stamp(4);
+    // ---- top-k of the fused scores over the union (ties: lower ordinal)
     uint32_t members;
     uint64_t mx_f;
-    auto each_f = [&](auto f) {
-        for (uint32_t i = tid; i < (uint32_t)kFuseSlots; i += NT) f(fused_key(i));
-    };
     const uint64_t T_f = kth_largest_u64<NT>(each_f, h.k, ks, tid, &members, &mx_f);
+    stamp(5);
     const uint32_t n_out = min(h.k, members);
-    for (uint32_t i = tid; i < (uint32_t)kFuseSlots; i += NT) {
-        const uint64_t key = fused_key(i);
+    each_f([&](const uint64_t key) {
         if (key && key >= T_f) {
             const uint32_t pos = atomicAdd(&red[3], 1u);
             if (pos < (uint32_t)kCandCap) cand[pos] = key;
         }
-    }
-    __syncthreads();
-    uint64_t* const res = reinterpret_cast<uint64_t*>(hkey);  // (the table is dead: 4096 x 4 B = 2048 keys >= k)
+    });
     __syncthreads();
     rank_and_emit<NT, true>(cand, (int)n_out, (int)h.k, res, tid);
     __syncthreads();
@@ -1606,6 +1601,7 @@ __global__ __launch_bounds__(NT) void hybrid_fuse_query(const HybridArgs h, cons
         h.out_n[q] = (int32_t)n_out;
         h.flags[q] = 0;
     }
+    stamp(6);
 }
 
 // rows of the passage matrix in ORDINAL order: P_ord[row2ord[r]] = P[r]
@@ -1903,20 +1899,20 @@ static int hybrid_search_multitile(msr_index* ix, msr_dense* dx, const int64_t* 
     const uint32_t quota_last = n_tiles > 1 ? std::min(quota_full, tile_quota(last_docs, n, (uint32_t)depth)) : quota_full;
     // candidate slots: a chunk of the first round (qc rows x quota_full) or at least ONE row of the second (depth)
     const size_t per_tile_row = (size_t)n_tiles;
-    const size_t cand_slots = std::max<size_t>((size_t)qc * per_tile_row * quota_full, per_tile_row * (size_t)depth);
+    // record slots (a tile's union of two candidate sets: 2 x quota): a chunk of the first round or at least ONE row of the second
+    const size_t cand_slots = 2 * std::max<size_t>((size_t)qc * per_tile_row * quota_full, per_tile_row * (size_t)depth);
     const size_t perk = std::max<size_t>((size_t)nq * k, 1);
     _Float16* d_Q = (_Float16*)dx->take(msr_dense::S_Q, std::max<size_t>((size_t)nq_pad * dx->h * 2, 16));
     uint32_t* d_S = (uint32_t*)dx->take(msr_dense::S_S, (size_t)qc * ld * 4);
     uint32_t* d_ord = (uint32_t*)dx->take(msr_dense::S_ORD, perk * 4);
     float* d_sf = (float*)dx->take(msr_dense::S_SF, perk * 4);
     int32_t* d_n = (int32_t*)dx->take(msr_dense::S_N, std::max<size_t>(nq, 1) * 4);
-    uint64_t* d_cs = (uint64_t*)dx->take(msr_dense::S_CS, cand_slots * 8);
-    uint64_t* d_cd = (uint64_t*)dx->take(msr_dense::S_CD, cand_slots * 8);
+    uint32_t* d_rec = (uint32_t*)dx->take(msr_dense::S_CS, cand_slots * 12);  // ordinals | sparse scores | dense keys
     uint4* d_meta = (uint4*)dx->take(msr_dense::S_META, std::max<size_t>((size_t)qc * per_tile_row * 2 * 16, 32));
     uint32_t* d_flags = (uint32_t*)dx->take(msr_dense::S_FLAGS, std::max<size_t>(nq, 1) * 4);
     uint32_t* d_qlist = (uint32_t*)dx->take(msr_dense::S_QLIST, std::max<size_t>(nq, 1) * 4);
     int32_t* d_self = nullptr;
-    bool ok = d_Q && d_S && d_ord && d_sf && d_n && d_cs && d_cd && d_meta && d_flags && d_qlist;
+    bool ok = d_Q && d_S && d_ord && d_sf && d_n && d_rec && d_meta && d_flags && d_qlist;
     if (ok && self_ord)
         ok = (d_self = (int32_t*)dx->take(msr_dense::S_SELF, std::max<size_t>(nq, 1) * 4)) != nullptr &&
              hipMemcpyAsync(d_self, self_ord, (size_t)nq * 4, hipMemcpyHostToDevice, d->stream) == hipSuccess;
@@ -1964,14 +1960,20 @@ static int hybrid_search_multitile(msr_index* ix, msr_dense* dx, const int64_t* 
     ha.out_score = d_sf;
     ha.out_n = d_n;
     ha.qlist = nullptr;
-    ha.cand_s = d_cs;
-    ha.cand_d = d_cd;
+    ha.rec_ord = d_rec;
+    ha.rec_s = d_rec + cand_slots;
+    ha.rec_d = d_rec + 2 * cand_slots;
     ha.tile_meta = d_meta;
     ha.n_tiles = n_tiles;
-    ha.stride = quota_full;
+    ha.stride = 2 * quota_full;
     ha.quota_full = quota_full;
     ha.quota_last = quota_last;
     ha.flags = d_flags;
+    unsigned long long* d_fq = nullptr;
+    if (getenv("MSR_DEBUG_HYBRID") && hipMalloc(&d_fq, 8 * sizeof(unsigned long long)) == hipSuccess) {
+        (void)hipMemsetAsync(d_fq, 0, 8 * sizeof(unsigned long long), d->stream);
+        ha.fq_stamps = d_fq;
+    }
     // one pass of the three kernels over `rows` launch rows (queries q0 .. or the listed ones), dense rows from d_Qrows
     auto launch_rows = [&](const _Float16* d_Qrows, uint32_t rows, uint32_t q0, hipEvent_t* e) -> int {
         const uint32_t rows_pad = (rows + 255) / 256 * 256;
@@ -1997,7 +1999,11 @@ static int hybrid_search_multitile(msr_index* ix, msr_dense* dx, const int64_t* 
             return MSR_E_HIP;
         }
         if (e) (void)hipEventRecord(e[2], d->stream);
-        hipLaunchKernelGGL((hybrid_fuse_query<256>), dim3(rows), dim3(256), 0, d->stream, ha, q0);
+        // (a query's records stay in registers while they fit: 16 per thread)
+        if ((uint64_t)ha.n_tiles * ha.stride <= 256u * 16u)
+            hipLaunchKernelGGL((hybrid_fuse_query<256, 16>), dim3(rows), dim3(256), 0, d->stream, ha, q0);
+        else
+            hipLaunchKernelGGL((hybrid_fuse_query<512, 16>), dim3(rows), dim3(512), 0, d->stream, ha, q0);
         if (hipGetLastError() != hipSuccess) {
             set_error("hybrid_fuse_query launch failed: %s", hipGetErrorString(hipGetLastError()));
             return MSR_E_HIP;
@@ -2048,9 +2054,10 @@ static int hybrid_search_multitile(msr_index* ix, msr_dense* dx, const int64_t* 
     if (dbg) fprintf(stderr, "[msr] hybrid multi-tile: %u tiles, quota %u / %u of depth %d, %u queries per chunk, %zu of %d "
                              "queries repeated with quota = depth\n", n_tiles, quota_full, quota_last, depth, qc, redo.size(), nq);
     if (rc == MSR_OK && !redo.empty()) {
-        const uint32_t rows_cap = (uint32_t)std::min<size_t>(std::min<size_t>(cand_slots / (per_tile_row * (size_t)depth), qc), redo.size());
+        const uint32_t rows_cap = (uint32_t)std::min<size_t>(std::min<size_t>(cand_slots / (2 * per_tile_row * (size_t)depth), qc), redo.size());
         std::vector<uint16_t> qrows((size_t)rows_cap * dx->h);
-        ha.stride = ha.quota_full = ha.quota_last = (uint32_t)depth;
+        ha.quota_full = ha.quota_last = (uint32_t)depth;
+        ha.stride = 2 * (uint32_t)depth;
         ha.qlist = d_qlist;
         for (size_t at = 0; at < redo.size() && rc == MSR_OK; at += rows_cap) {
             const uint32_t rows = (uint32_t)std::min<size_t>(rows_cap, redo.size() - at);
@@ -2106,6 +2113,14 @@ static int hybrid_search_multitile(msr_index* ix, msr_dense* dx, const int64_t* 
         ms[1] = t_gemm;
         ms[2] = 0.f;
         ms[3] = t_fuse;
+    }
+    if (d_fq) {
+        unsigned long long st[8] = {0};
+        (void)hipMemcpy(st, d_fq, sizeof(st), hipMemcpyDeviceToHost);
+        fprintf(stderr, "[msr] hybrid_fuse_query thread-0 clocks (1 workgroup in 16): load+init %llu, sparse depth-th %llu, dense "
+                        "depth-th %llu, verify %llu, fusion %llu, fused k-th %llu, collect+rank+store %llu\n",
+                st[0], st[1], st[2], st[3], st[4], st[5], st[6]);
+        (void)hipFree(d_fq);
     }
     for (hipEvent_t x : ev) {
         if (!x) continue;
