@@ -492,6 +492,7 @@ def cpu_baseline(wl, got, target_seconds, threads, rows=True):
 
     def sized(thr, per_call=None, mode="exhaustive"):
         """queries that fill ~target_seconds at this setting (from a short probe)"""
+        nonlocal target_seconds
         probe = min(nq, max(4 * thr, 64))
         t1 = time.perf_counter()
         if per_call:
@@ -532,6 +533,22 @@ def cpu_baseline(wl, got, target_seconds, threads, rows=True):
                           "kind": "port", "identical_to_exhaustive": bool((r2[0][:nn] == w_ord[:nn]).all() and (r2[1][:nn] == w_sc[:nn]).all()),
                           "shape": f"one call, {thr_all} threads = every CPU this job may run on (sched_getaffinity); "
                                    f"term-at-a-time, only touched docs scanned and cleared"})
+        # thread-count scan of the exhaustive port (the strongest row is the honest "what this host can do" figure;
+        # `value` stays at the reference's --threads 16)
+        scan = []
+        for thr in (32, 64, 128):
+            if thr < thr_all and thr != threads:
+                save, target_seconds = target_seconds, min(target_seconds, 2.0)
+                n5 = sized(thr)
+                target_seconds = save
+                t0 = time.perf_counter()
+                oix.search(*sub(0, n5), wl.k, threads=thr)
+                d5 = time.perf_counter() - t0
+                scan.append({"cores": thr, "value": round(n5 / max(d5, 1e-9), 1), "queries": n5, "seconds": round(d5, 2)})
+        if scan:
+            best = max(scan + [{"cores": threads, "value": cb["value"]}], key=lambda r: r["value"])
+            extra.append({"kind": "port", "shape": "thread-count scan of the exhaustive port, one call each", "scan": scan,
+                          "best": {"cores": best["cores"], "value": best["value"]}})
         # a PRUNING engine on the same host: document-at-a-time MaxScore in 4096-doc windows (the strategy of Lucene's
         # bulk scorer for pure disjunctions), exact, same file. With ~flat learned-sparse weights few lists ever become
         # non-essential at k = 10, so pruning does not beat the exhaustive scan here: reported, not assumed.
@@ -553,6 +570,10 @@ def cpu_baseline(wl, got, target_seconds, threads, rows=True):
                       "shape": f"4 queries per call, {threads} threads (the reference's per_device_batch_size 4 / "
                                f"--threads 16, scripts/search_sparse.sh:16-17)"})
         cb["rows"] = extra
+        # the strongest CPU figure of this host over every row (one big call): what the GPU number should be held against
+        one_call = [cb["value"]] + [r["value"] for r in extra if "value" in r and "4 queries per call" not in r.get("shape", "")]
+        one_call += [r["best"]["value"] for r in extra if "best" in r]
+        cb["best_one_call_value"] = max(one_call)
     return cb, {"checked_queries": n, "mismatches": mism}
 
 
@@ -610,6 +631,7 @@ def run_headline(args, ranks, m, wlmod):
             out["cpu_baseline"] = cb
             out["parity"] = par
             out["speedup_vs_cpu"] = round(out["value"] / cb["value"], 1)
+            out["speedup_vs_best_cpu_row"] = round(out["value"] / cb["best_one_call_value"], 1)
         if ranks.world == 1 and not args.no_cpu:  # (--no-cpu = profiling runs: only the timed launches)
             # PCIe-inclusive figures (never `value`): host CSR in -> host results out through msr_search_csr, and the
             # reference's own call shape of 4 queries per batch_search call (scripts/search_sparse.sh:16)
@@ -782,6 +804,7 @@ def run_c4(args, ranks, m, wlmod, status):
                 out["cpu_baseline"] = cb
                 out["parity"] = par
                 out["speedup_vs_cpu"] = round(out["value"] / cb["value"], 1)
+                out["speedup_vs_best_cpu_row"] = round(out["value"] / cb["best_one_call_value"], 1)
         doc_sharded_result = batch.fetch() if sharded else fallback_result.get("r")
         batch.close()
         if sharded:

@@ -1289,6 +1289,75 @@ def test_fused_hybrid_tightly_clustered_scores(m, tmp_path):
         dix.close()
 
 
+def test_multitile_hybrid_randomised(m, tmp_path, monkeypatch):
+    """Fuzz of the candidate kernels (hybrid_tiles<MODE 1> + hybrid_fuse_query) against the oracle pipeline: 2-5 tiles of
+    4096 or 8192 docs incl. a last tile of one doc, depths 1-1024, k 1-1024, alpha incl. 0 and 1, remove_query, empty and
+    short queries, small vocabularies (mass ties on the sparse side), duplicated passage rows (exact dense ties), and — every
+    third case — a forced quota of 1-40 candidates per tile, so that hybrid_fuse_query's verification has to send queries
+    to the second round. (MSR_FUZZ_SEED / MSR_FUZZ_CASES as in the other fuzz tests.)"""
+    from mllm_sparse_retrieval_amd.dense import DenseIndex, hybrid_search, row_to_ordinal
+
+    rng = np.random.default_rng(int(os.environ.get("MSR_FUZZ_SEED", "20261005")))
+    for case in range(int(os.environ.get("MSR_FUZZ_CASES", "12"))):
+        tile = int(rng.choice([4096, 8192]))
+        n = int(rng.choice([tile + 1, tile + 700, 2 * tile, 2 * tile + 1, 3 * tile - 5, 4 * tile + 33]))
+        n_terms = int(rng.choice([6, 60, 2000]))
+        nnz = int(min(n_terms, rng.integers(1, 20)))
+        nq = int(rng.integers(3, 24))
+        qn = int(min(n_terms, rng.integers(0, 12)))
+        depth = int(rng.choice([1, 7, 100, 1000, 1024]))
+        k = int(rng.choice([1, 10, 64, 200, 1024]))
+        alpha = float(rng.choice([0.0, 0.3, 0.5, 1.0]))
+        remove = bool(rng.integers(0, 2))
+        h = int(rng.choice([32, 64]))
+        if case % 3 == 2:
+            monkeypatch.setenv("MSR_HYBRID_QUOTA", str(int(rng.integers(1, 41))))
+        else:
+            monkeypatch.delenv("MSR_HYBRID_QUOTA", raising=False)
+        dp = np.arange(0, n * nnz + 1, nnz, dtype=np.uint64)
+        dt = (rng.integers(0, n_terms, (n, 1)) + np.arange(nnz)[None, :] * max(n_terms // max(nnz, 1), 1)) % n_terms
+        dt = np.sort(dt, axis=1)
+        if nnz > 1 and (np.diff(dt, axis=1) == 0).any():   # (distinct terms per row)
+            dt = np.stack([rng.choice(n_terms, nnz, replace=False) for _ in range(n)])
+        dt = dt.astype(np.uint32).ravel()
+        dw = rng.integers(1, 300, n * nnz).astype(np.uint32)
+        qp = np.arange(nq + 1, dtype=np.int64) * qn
+        qt = rng.integers(0, n_terms, nq * qn).astype(np.int32)
+        qw = rng.integers(0, 50, nq * qn).astype(np.int32)
+        ids = [str(int(x)) for x in rng.permutation(n * 3)[:n]]
+        path = m.build_index_from_csr(str(tmp_path / f"mz{case}.idx"), dp, dt, dw, n_terms, doc_ids=ids, tile_docs=tile)
+        p = _unit_rows(rng, n, h)
+        if case % 4 == 0:
+            p[1::2] = p[0::2][: len(p[1::2])]                               # every passage row twice: exact dense ties
+        q = _unit_rows(rng, nq, h)
+        qids = [ids[i] for i in range(nq)]
+        with m.SparseIndex(path, device=0) as ix:
+            assert ix.n_tiles == (n + tile - 1) // tile >= 2
+            dix = DenseIndex(p)
+            r2o = row_to_ordinal(ix, ids)
+            self_ord = np.array([int(r2o[i]) for i in range(nq)], dtype=np.int32) if remove else None
+            ords, fs, cnt, ms = hybrid_search(ix, dix, qp, qt, qw, q, depth, k, alpha, r2o, self_ord)
+            assert ms["dense_select"] == 0 and ms["fusion"] > 0
+            docid_of = ix.docid
+            want, sq = helpers.oracle_hybrid((dp, dt, dw), n_terms, ids, qp, qt, qw, q, p, depth, alpha, np.arange(nq),
+                                             remove, qids, dense_tie_key=r2o)
+            dsc_o, _ = helpers.dense_oracle(q, p, min(depth, n), r2o)
+            spread = np.maximum(dsc_o[:, 0] - dsc_o[:, -1], 1e-3)
+            for i in range(nq):
+                tol = 1e-5 + alpha * 1e-6 / float(spread[i])
+                ranked = sorted(want[sq[i]].items(), key=lambda kv: (-float(kv[1]), kv[0].encode()))[:k]
+                assert cnt[i] == len(ranked), (case, i, cnt[i], len(ranked))
+                got = [docid_of(int(o)) for o in ords[i, : cnt[i]]]
+                assert len(set(got)) == len(got)
+                for r, (doc, score) in enumerate(ranked):
+                    assert abs(float(fs[i, r]) - float(score)) <= tol, (case, i, r, float(fs[i, r]), float(score), tol)
+                if remove:
+                    assert qids[i] not in got
+            dix.close()
+        os.remove(path)
+    monkeypatch.delenv("MSR_HYBRID_QUOTA", raising=False)
+
+
 def test_fused_hybrid_mass_ties(m, tmp_path):
     """Every doc holds the same term with the same weight: all sparse scores tie, so the sparse top-`depth` list is the
     `depth` LOWEST ordinals (doc-id string order) — the selection's histogram collapses into one bin and has to split
