@@ -1166,6 +1166,7 @@ __global__ __launch_bounds__(NT, MIN_WAVES) void hybrid_tiles(const ScoreArgs a,
             m[0] = make_uint4((uint32_t)ws, (uint32_t)(ws >> 32), n_s, need_s == n_s ? 1u : 0u);
             m[1] = make_uint4((uint32_t)wd, (uint32_t)(wd >> 32), n_d, need_d == n_d ? 1u : 0u);
         }
+        stamp(2);
         return;
     }
     // ---- fusion (src/hybrid.py:32-53): min = the last member's score, max = the best, per side; fused keys go to the
@@ -1970,8 +1971,8 @@ static int hybrid_search_multitile(msr_index* ix, msr_dense* dx, const int64_t* 
     ha.quota_last = quota_last;
     ha.flags = d_flags;
     unsigned long long* d_fq = nullptr;
-    if (getenv("MSR_DEBUG_HYBRID") && hipMalloc(&d_fq, 8 * sizeof(unsigned long long)) == hipSuccess) {
-        (void)hipMemsetAsync(d_fq, 0, 8 * sizeof(unsigned long long), d->stream);
+    if (getenv("MSR_DEBUG_HYBRID") && hipMalloc(&d_fq, 16 * sizeof(unsigned long long)) == hipSuccess) {
+        (void)hipMemsetAsync(d_fq, 0, 16 * sizeof(unsigned long long), d->stream);
         ha.fq_stamps = d_fq;
     }
     // one pass of the three kernels over `rows` launch rows (queries q0 .. or the listed ones), dense rows from d_Qrows
@@ -1989,8 +1990,11 @@ static int hybrid_search_multitile(msr_index* ix, msr_dense* dx, const int64_t* 
                 return MSR_E_RANGE;
             }
             const dim3 grid(rows, n_tiles);
+            sa.stamps = reinterpret_cast<unsigned long long*>(ha.fq_stamps ? ha.fq_stamps + 8 : nullptr);
             if (tile == 4096)
                 hipLaunchKernelGGL((hybrid_tiles<4096, 256, 4, 5, false, 1>), grid, dim3(256), 0, d->stream, sa, ha);
+            else if (sa.stamps)  // diagnostic (MSR_DEBUG_HYBRID): wave 0 of one workgroup in 64 adds its phase clocks
+                hipLaunchKernelGGL((hybrid_tiles<8192, 512, 4, 6, true, 1>), grid, dim3(512), 0, d->stream, sa, ha);
             else
                 hipLaunchKernelGGL((hybrid_tiles<8192, 512, 4, 6, false, 1>), grid, dim3(512), 0, d->stream, sa, ha);
         }
@@ -2115,8 +2119,10 @@ static int hybrid_search_multitile(msr_index* ix, msr_dense* dx, const int64_t* 
         ms[3] = t_fuse;
     }
     if (d_fq) {
-        unsigned long long st[8] = {0};
+        unsigned long long st[16] = {0};
         (void)hipMemcpy(st, d_fq, sizeof(st), hipMemcpyDeviceToHost);
+        fprintf(stderr, "[msr] hybrid_tiles<MODE 1> wave-0 clocks (1 workgroup in 64): accumulate + dense row %llu, dual quota "
+                        "selection %llu, emission %llu\n", st[8], st[9], st[10]);
         fprintf(stderr, "[msr] hybrid_fuse_query thread-0 clocks (1 workgroup in 16): load+init %llu, sparse depth-th %llu, dense "
                         "depth-th %llu, verify %llu, fusion %llu, fused k-th %llu, collect+rank+store %llu\n",
                 st[0], st[1], st[2], st[3], st[4], st[5], st[6]);
