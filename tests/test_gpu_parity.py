@@ -1125,6 +1125,38 @@ def test_multitile_hybrid_vs_oracle_pipeline(m, tmp_path, n, tile, depth, k, alp
     assert tiles == (n + (tile or 8192) - 1) // (tile or 8192)
 
 
+def test_multitile_hybrid_edges(m, tmp_path):
+    """The candidate kernels at the edges: no queries at all, a corpus of one / three docs (k > 64 sends even a single tile
+    down this path), depth and k larger than the corpus, every query empty on the sparse side."""
+    from mllm_sparse_retrieval_amd.dense import DenseIndex, hybrid_search, row_to_ordinal
+
+    for n in (1, 3, 4097):
+        tiles = _hybrid_case(m, tmp_path, n, 4096, min(n, 8), 1024, 100, 0.5, n > 1, n_terms=50, doc_nnz=min(5, 50),
+                             q_nnz=3, expect="multi")
+        assert tiles == (n + 4095) // 4096
+    docs, (qp, qt, qw) = helpers.synth(9000, 16, 6, 4, 300, seed=5)
+    path = m.build_index_from_csr(str(tmp_path / "e.idx"), *docs, 300, tile_docs=4096)
+    rng = np.random.default_rng(1)
+    p, q = _unit_rows(rng, 9000, 32), _unit_rows(rng, 6, 32)
+    with m.SparseIndex(path, device=0) as ix:
+        dix = DenseIndex(p)
+        r2o = row_to_ordinal(ix, [str(i) for i in range(9000)])
+        # no queries
+        o, f, c, ms = hybrid_search(ix, dix, np.zeros(1, np.int64), np.zeros(0, np.int32), np.zeros(0, np.int32),
+                                    np.zeros((0, 32), np.float32), 100, 10, 0.5, r2o)
+        assert o.shape == (0, 10) and c.shape == (0,)
+        # queries without a single sparse term: the union is the dense depth list alone
+        o, f, c, ms = hybrid_search(ix, dix, np.zeros(7, np.int64), np.zeros(0, np.int32), np.zeros(0, np.int32), q, 50, 64,
+                                    0.5, r2o)
+        assert (c == 50).all() and ms["fusion"] > 0
+        sfull = q.astype(np.float16).astype(np.float32) @ p.astype(np.float16).astype(np.float32).T
+        for i in range(6):
+            top = np.argsort(-sfull[i], kind="stable")[:50]
+            assert set(int(r2o[r]) for r in top) == set(int(x) for x in o[i, :50])
+            assert abs(float(f[i, 0]) - 0.5) <= 1e-6 and float(f[i, 49]) == 0.0   # min-max: best = alpha, the 50th = 0
+        dix.close()
+
+
 def test_multitile_hybrid_second_round(m, tmp_path, monkeypatch):
     """A quota too small for the depth lists (forced through MSR_HYBRID_QUOTA): hybrid_fuse_query flags every query and
     the second round (every tile emits its own top-depth) produces the same exact result; and sparse lists that live in
