@@ -455,7 +455,8 @@ static int batch_create_impl(msr_index* ix, const int64_t* q_ptr, const int32_t*
         int rc = MSR_OK;
         char err[192] = {0};
     };
-    const int n_parts = (nq >= 8192 && total_in >= (1 << 16)) ? std::min(clamp_threads(0), 16) : 1;
+    // (by entries, not by queries: 5 000 hybrid queries of 120 terms are as much work as 60 000 captions)
+    const int n_parts = (nq >= 64 && total_in >= (1 << 16)) ? std::min(std::min(clamp_threads(0), 16), nq / 16) : 1;
     std::vector<Part> parts((size_t)n_parts);
     auto normalise = [&](int pi) {
         Part& pt = parts[(size_t)pi];
