@@ -145,3 +145,46 @@ def test_tie_order_switch_numbers_docs_in_input_order(tmp_path):
         m.set_build_option("tie_order", 0)
     assert helpers.read_index_file(a)["docs"] == sorted(ids, key=lambda s: s.encode())   # "10" < "100" < "2" < "9"
     assert helpers.read_index_file(b)["docs"] == ids
+
+
+def test_encode_queries_in_c_equals_the_python_tokeniser(m, tmp_path):
+    """msr_encode_queries (query strings -> CSR, tokenised and looked up in C, on several threads from 64 queries on)
+    against the Python restatement of pyserini's token-frequency encoding (searcher.tokenize_queries + lookup): tokens
+    repeated `weight` times in a row (src/search.py:419-422), repeats that are NOT adjacent, out-of-vocabulary tokens,
+    every ASCII whitespace, empty strings. No GPU needed: the handle is opened with device = -1."""
+    from mllm_sparse_retrieval_amd.searcher import tokenize_queries
+
+    rng = np.random.default_rng(3)
+    vocab = [f"t{i}" for i in range(200)] + ["ġdog", "▁cat", "a-b", "7"]
+    n_terms = len(vocab)
+    dp = np.arange(0, 2 * 300 + 1, 2, dtype=np.uint64)
+    dt = rng.integers(0, n_terms, 600).astype(np.uint32)
+    dt[:n_terms] = np.arange(n_terms)                      # every term occurs (else it is not in the dictionary)
+    dw = np.ones(600, dtype=np.uint32)
+    path = m.build_index_from_csr(str(tmp_path / "q.idx"), dp, dt, dw, n_terms, term_strs=vocab, tile_docs=4096)
+    queries = []
+    for i in range(150):
+        toks = []
+        for _ in range(int(rng.integers(0, 12))):
+            tok = vocab[int(rng.integers(0, n_terms))] if rng.random() < 0.8 else f"oov{int(rng.integers(0, 5))}"
+            toks += [tok] * int(rng.integers(1, 6))         # the reference writes a token `weight` times in a row
+        if rng.random() < 0.3:
+            rng.shuffle(toks)                               # ... and a query whose repeats are scattered
+        sep = [" ", "  ", "\t", "\n ", " \r"][i % 5]
+        queries.append(sep.join(toks) + ("  " if i % 7 == 0 else ""))
+    queries[10] = ""
+    queries[11] = "   \t "
+    with m.SparseIndex(path, device=-1) as ix:
+        for qs in (queries, queries[:5], []):               # threaded, serial, empty
+            q_ptr, q_term, q_w = ix.encode_queries(qs)
+            w_ptr, w_toks, w_w = tokenize_queries(qs)
+            w_term = ix.lookup(w_toks)
+            assert len(q_ptr) == len(qs) + 1 and q_ptr[0] == 0
+            for i in range(len(qs)):
+                got = dict(zip(q_term[q_ptr[i]:q_ptr[i + 1]].tolist(), q_w[q_ptr[i]:q_ptr[i + 1]].tolist()))
+                want = {}
+                for t, w in zip(w_term[w_ptr[i]:w_ptr[i + 1]].tolist(), w_w[w_ptr[i]:w_ptr[i + 1]].tolist()):
+                    if t >= 0:                              # the C encoder drops out-of-vocabulary tokens (contract T2)
+                        want[t] = want.get(t, 0) + w
+                assert got == want, (i, qs[i])
+                assert len(got) == q_ptr[i + 1] - q_ptr[i]   # one entry per distinct term
