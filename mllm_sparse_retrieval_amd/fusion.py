@@ -1,4 +1,4 @@
-"""Hybrid fusion and TREC run files — the reference's src/hybrid.py:8-53 semantics.
+"""Hybrid fusion and TREC run files — the reference's src/hybrid.py:8-90 semantics.
 
 fuse(): for every doc in the union of the runs' result lists, sum over runs of
     weight * (score - min_score) / max(max_score - min_score, 1e-9)   if the run retrieved the doc, else 0,
@@ -26,6 +26,46 @@ def fuse(runs, weights):
                     if s is not None:
                         total += weight * ((s - lo) / den)
                 acc[doc] = total
+        fused[qid] = acc
+    return fused
+
+
+class ResultRecord:
+    """src/hybrid.py:3-6: a fused score and where it came from ('dense', 'sparse' or 'fuse' = both lists held the doc)."""
+
+    __slots__ = ("score", "type")
+
+    def __init__(self, score, type):
+        self.score = score
+        self.type = type
+
+    def __repr__(self):
+        return f"ResultRecord(score={self.score}, type={self.type!r})"
+
+
+def fuse_statistic(runs, weights):
+    """src/hybrid.py:56-90 (used by the reference's score_statistic.py): fuse() that also says which run(s) a doc's
+    score came from. A doc found in exactly one run is tagged by the POSITION of the run being walked when the doc is
+    first met ('dense' while walking runs[0], 'sparse' afterwards), as the reference does; found in more: 'fuse'."""
+    qids = set()
+    for run in runs:
+        qids.update(run)
+    fused = {}
+    for qid in qids:
+        acc = {}
+        spans = [(r[qid]["min_score"], max(r[qid]["max_score"] - r[qid]["min_score"], 1e-9)) for r in runs]
+        for position, run in enumerate(runs, start=1):
+            for doc in run[qid]["docs"]:
+                if doc in acc:
+                    continue
+                total, found = 0, 0
+                for other, weight, (lo, den) in zip(runs, weights, spans):
+                    s = other[qid]["docs"].get(doc)
+                    if s is not None:
+                        total += weight * ((s - lo) / den)
+                        found += 1
+                kind = ("dense" if position == 1 else "sparse") if found == 1 else "fuse"
+                acc[doc] = ResultRecord(total, kind)
         fused[qid] = acc
     return fused
 

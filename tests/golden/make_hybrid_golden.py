@@ -5,6 +5,7 @@ Run in the build container only (it needs /root/reference, which never travels t
     python tests/golden/make_hybrid_golden.py
 It imports /root/reference/src/hybrid.py (argparse + tqdm only) and records, for seeded random inputs:
   - fuse(runs, weights)                      src/hybrid.py:32-53
+  - fuse_statistic(runs, weights)            src/hybrid.py:56-90  (as {qid: {doc: [score, type]}})
   - write_trec_run(run, file, name) text     src/hybrid.py:20-29
   - read_trec_run(file) of that text         src/hybrid.py:8-17
 The JSON holds inputs and outputs only (data, no reference source).
@@ -59,6 +60,7 @@ def main():
                     q["min_score"] = q["max_score"]
         weights = [alpha, 1 - alpha]
         fused = ref.fuse([dense, sparse], weights)
+        stat = {q: {d: [r.score, r.type] for d, r in v.items()} for q, v in ref.fuse_statistic([dense, sparse], weights).items()}
         with tempfile.TemporaryDirectory() as d:
             f1 = os.path.join(d, "sparse.trec")
             ref.write_trec_run(sparse, f1, name="sparse")
@@ -67,7 +69,7 @@ def main():
             f2 = os.path.join(d, "fusion.trec")
             ref.write_trec_run(fused, f2)
             fused_text = open(f2).read()
-        cases.append(dict(dense=dense, sparse=sparse, weights=weights, fused=fused, sparse_trec=sparse_text,
+        cases.append(dict(dense=dense, sparse=sparse, weights=weights, fused=fused, fused_statistic=stat, sparse_trec=sparse_text,
                           sparse_trec_read=sparse_back, fused_trec=fused_text))
     json.dump({"generator": "tests/golden/make_hybrid_golden.py", "reference": "src/hybrid.py @ 2025-04-18",
                "cases": cases}, open(OUT, "w"), indent=1)  # key order is data: it is the tie order of later stable sorts

@@ -32,6 +32,20 @@ def test_fuse_matches_reference_bit_for_bit(hybrid_cases):
             assert list(got[qid]) == list(c["fused"][qid])
 
 
+def test_fuse_statistic_matches_reference(hybrid_cases):
+    """src/hybrid.py:56-90 (the variant score_statistic.py uses): the same fused scores as fuse(), each tagged 'dense' /
+    'sparse' / 'fuse'; recorded by running the reference's own function (tests/golden/make_hybrid_golden.py)."""
+    for c in hybrid_cases:
+        got = fusion.fuse_statistic([c["dense"], c["sparse"]], c["weights"])
+        assert {q: {d: [r.score, r.type] for d, r in v.items()} for q, v in got.items()} == c["fused_statistic"]
+        assert {q: {d: r.score for d, r in v.items()} for q, v in got.items()} == c["fused"]
+        for qid in got:
+            assert list(got[qid]) == list(c["fused_statistic"][qid])      # union order: dense docs first
+            for doc, rec in got[qid].items():
+                in_d, in_s = doc in c["dense"][qid]["docs"], doc in c["sparse"][qid]["docs"]
+                assert rec.type == ("fuse" if in_d and in_s else "dense" if in_d else "sparse")
+
+
 def test_trec_io_matches_reference(hybrid_cases, tmp_path):
     for i, c in enumerate(hybrid_cases):
         f = tmp_path / f"s{i}.trec"
