@@ -967,15 +967,37 @@ def run_c5(args, ranks, m, wlmod, shape="t2i"):
               (("hybrid_tiles_mode1", "hybrid_tiles", "sparse"), ("hybrid_fuse_query", "hybrid_fuse_query", "fusion")) if multi else
               (("dense_select", "select_tiles", "dense_select"), ("fusion", "fuse_tiles", "fusion"),
                ("sparse", "score_tiles", "sparse")))
+    # the sparse work of one search (the hybrid kernels run the search path's accumulation): postings by pipe, accumulator tiles
+    wb = ix.batch(qp, qt, qw, 1)
+    work = wb.work()
+    wb.close()
+    pk = pipe_peaks()
     for stage, kre, key in stages:
         if ms.get(key, 0) > 0:
             fr = binding_fractions(counters(wname, kre), ms[key])
             cands = {b: fr.get(k3) for b, k3 in (("hbm", "hbm_frac"), ("l2", "l2_frac"), ("valu", "valu_busy"))
                      if fr.get(k3) is not None}
-            bound = max(cands, key=cands.get) if cands else None
-            # (pipe utilisation — how busy, not how useful: no `frac` is claimed for these kernels)
-            rl[stage] = {"bound": bound, "frac": None, "busiest_pipe_utilisation": cands.get(bound) if bound else None,
+            busiest = max(cands, key=cands.get) if cands else None
+            rl[stage] = {"bound": busiest, "frac": None, "busiest_pipe_utilisation": cands.get(busiest) if busiest else None,
                          "kernel_ms": round(ms[key], 4), "utilisation": fr}
+            # useful-work fraction as for score_tiles (sparse_roofline), for the kernels that score: the accumulator tile
+            # is written twice (init, fused keys) and read four times (two selection passes, fusion, final collection)
+            # by hybrid_tiles, written once and read three times (two selection passes, emission) by its MODE 1
+            passes = {"hybrid_tiles": 6, "hybrid_tiles_mode1": 4}.get(stage)
+            if passes and pk.get("ds_add_per_s"):
+                min_ms = {"lds_atomic": work["sparse_postings"] / pk["ds_add_per_s"] * 1e3,
+                          "valu_dot2": work["dense_head_postings"] / 2.0 / pk["dot2_per_s"] * 1e3,
+                          "lds_bw": work["acc_init_bytes"] * passes / pk["lds_bytes_per_s"] * 1e3}
+                if fr.get("traffic") is not None:
+                    min_ms["hbm"] = fr["traffic"] / (HBM_PEAK_GBS * 1e9) * 1e3
+                bound = max(min_ms, key=min_ms.get)
+                complete = "hbm" in min_ms and not counters_state()["stale"]
+                rl[stage].update(bound=bound, frac=round(min_ms[bound] / ms[key], 4) if complete else None,
+                                 useful={"min_ms_per_pipe": {b: round(v, 4) for b, v in min_ms.items()},
+                                         "accumulator_passes": passes, "work_per_search": work,
+                                         "note": "binding pipe's minimum time at the measured instruction peaks / kernel time; "
+                                                 "the two depth-1000 selections and the fusion are this kernel's purpose but "
+                                                 "not 'work' in this sense: only their accumulator traffic is counted"})
     out["roofline"] = rl
     out["counters_stale"] = bool(counters_state()["stale"])
     if not args.no_cpu and shape == "i2t":
