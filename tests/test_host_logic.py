@@ -81,6 +81,59 @@ def test_sparse_search_and_run_dict():
     assert rd == oracle.get_run_dict(["9", "7", "8"], scores, rankings, True)
 
 
+def test_run_helpers_against_the_reference_functions(tmp_path):
+    """sparse_search / get_run_dict / search_queries / pickle_load against the outputs of the REFERENCE's own functions
+    (src/search.py:49-99), recorded by tests/golden/make_run_golden.py, which compiles exactly those four function bodies
+    out of the reference file's AST (the module itself cannot be imported here: faiss, pyserini, … are absent) and runs
+    them on seeded inputs: batch order != dict order, queries that find themselves (remove_query), empty hit lists,
+    repeated scores, integer lookup ids that become strings, batch_size 0 -> .search(), > 0 -> .batch_search()."""
+    import pickle
+
+    cases = json.load(open(os.path.join(GOLD, "run_golden.json")))["cases"]
+    assert [c["kind"] for c in cases].count("sparse") == 6
+    for c in cases:
+        if c["kind"] == "sparse":
+            table = {q: [(d, s) for d, s in hits] for q, hits in c["table"].items()}
+            args = SimpleNamespace(depth=c["depth"], threads=16)
+            for mod in (run, oracle):
+                topics = [f"topic {q}" for q in c["batch_ids"]]
+                scores, rankings = (run.sparse_search(_FakeSearcher(table), topics, c["batch_ids"], args) if mod is run else
+                                    oracle.sparse_search(_FakeSearcher(table), topics, c["batch_ids"], c["depth"], 16))
+                assert scores == c["scores"] and rankings == c["rankings"]
+                for rq in (False, True):
+                    got = mod.get_run_dict(c["batch_ids"], scores, rankings, rq)
+                    assert got == c["run_dict"][str(rq)]
+                    assert [list(got[q]["docs"]) for q in got] == [list(v["docs"]) for v in c["run_dict"][str(rq)].values()]
+        elif c["kind"] == "dense":
+            calls = []
+
+            class Fake:
+                def batch_search(self, q_reps, depth, batch_size, quiet):
+                    calls.append(["batch_search", int(depth), int(batch_size), bool(quiet)])
+                    return np.asarray(c["scores"], np.float32)[:, :depth], np.asarray(c["indices"])[:, :depth]
+
+                def search(self, q_reps, depth):
+                    calls.append(["search", int(depth)])
+                    return np.asarray(c["scores"], np.float32)[:, :depth], np.asarray(c["indices"])[:, :depth]
+
+            args = SimpleNamespace(depth=c["depth"], batch_size=c["batch_size"], quiet=True)
+            out_scores, out_ids = run.search_queries(Fake(), np.zeros((4, 16), np.float32), c["lookup"], args)
+            assert calls == c["calls"]
+            assert np.asarray(out_scores).tolist() == c["out_scores"]
+            assert out_ids.tolist() == c["out_ids"] and out_ids.dtype.kind == c["out_ids_dtype_kind"]
+            for rq in (False, True):
+                got = run.get_run_dict(c["batch_ids"], out_scores, out_ids, rq)
+                got = {q: {"docs": {d: float(v) for d, v in e["docs"].items()}, "min_score": float(e["min_score"]),
+                           "max_score": float(e["max_score"])} for q, e in got.items()}
+                assert got == c["run_dict"][str(rq)]
+        else:
+            path = tmp_path / "corpus_0.pkl"
+            with open(path, "wb") as f:
+                pickle.dump((np.asarray(c["reps"], np.float32), c["lookup"]), f)
+            reps, lookup = run.pickle_load(str(path))
+            assert reps.tolist() == c["got_reps"] and str(reps.dtype) == c["got_dtype"] and list(lookup) == c["got_lookup"]
+
+
 def test_query_tokenization_counts_repeats():
     q_ptr, toks, ws = tokenize_queries(["dog dog  cat", "", "a\tb a\n"])
     assert q_ptr.tolist() == [0, 2, 2, 4]
